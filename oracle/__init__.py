@@ -49,6 +49,8 @@ def lib():
         _lib.oracle_inflate.restype = ctypes.c_int
         _lib.oracle_inflate.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                         ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        _lib.oracle_inflate_ex.restype = ctypes.c_int
+        _lib.oracle_inflate_ex.argtypes = _lib.oracle_inflate.argtypes + [ctypes.c_int]
         _lib.oracle_inflate_chunk.restype = ctypes.c_int
         _lib.oracle_inflate_chunk.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                               ctypes.c_void_p, ctypes.c_size_t,
@@ -59,14 +61,19 @@ def lib():
     return _lib
 
 
-def inflate(data, out_cap=None):
-    """Inflate one raw DEFLATE stream. -> (status, output bytes, in_off, out_off)."""
+def inflate(data, out_cap=None, rfc_rep16=False):
+    """Inflate one raw DEFLATE stream. -> (status, output bytes, in_off, out_off).
+
+    rfc_rep16=False: the in-repo flate.Reader rule for code-length symbol 16;
+    True: the RFC 1951 / Go stdlib rule that xflate.Reader's inflater uses
+    (see read_prefix_codes in inflate_oracle.c)."""
     data = bytes(data)
     if out_cap is None:
         out_cap = max(1 << 16, len(data) * 1100)       # DEFLATE expands at most ~1032x
     out = ctypes.create_string_buffer(max(out_cap, 1))
     i, o = ctypes.c_int64(), ctypes.c_int64()
-    st = lib().oracle_inflate(data, len(data), out, out_cap, ctypes.byref(i), ctypes.byref(o))
+    st = lib().oracle_inflate_ex(data, len(data), out, out_cap, ctypes.byref(i), ctypes.byref(o),
+                                 1 if rfc_rep16 else 0)
     return st, out.raw[:o.value], i.value, o.value
 
 

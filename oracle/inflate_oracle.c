@@ -239,8 +239,20 @@ static void init_fixed(tables *t) {
     t->fixed_ready = 1;
 }
 
-/* flate/prefix.go:83-194. 0 ok, 1 corrupted, 2 unexpected EOF */
-static int read_prefix_codes(bitrd *br, tables *t) {
+/* flate/prefix.go:83-194. 0 ok, 1 corrupted, 2 unexpected EOF.
+ *
+ * rfc_rep16: what code-length symbol 16 ("copy the previous length") repeats
+ * after a 17/18 zero run.
+ *   0 = the in-repo flate package: clenLast is only updated by literal lengths
+ *       (flate/prefix.go:127-133,142), so it repeats the last LITERAL length;
+ *   1 = RFC 1951 / Go stdlib compress/flate, which is the inflater
+ *       xflate.Reader really calls (xflate/flate.go:9,43): it repeats the
+ *       previous entry of the length array, i.e. 0 after a zero run.
+ * zlib-style encoders never emit 16 after 17/18, but XFLATE meta blocks do
+ * (meta/writer.go:236-245), and xflate/reader_test.go:261-274 only passes with
+ * the stdlib rule ("raw chunk with final bit and bad size": its index block
+ * has a repLast after a repZero). */
+static int read_prefix_codes(bitrd *br, tables *t, int rfc_rep16) {
     uint32_t v;
     if (br_read_bits(br, 5, &v)) return ORC_UNEXPECTED_EOF;
     uint32_t num_lit = v + 257;
@@ -294,11 +306,13 @@ static int read_prefix_codes(bitrd *br, tables *t) {
                 clen = 0;
                 if (br_read_bits(br, 3, &v)) return ORC_UNEXPECTED_EOF;
                 rep_cnt = 3 + v;
+                if (rfc_rep16) clen_last = 0;
                 break;
             case 18:
                 clen = 0;
                 if (br_read_bits(br, 7, &v)) return ORC_UNEXPECTED_EOF;
                 rep_cnt = 11 + v;
+                if (rfc_rep16) clen_last = 0;
                 break;
             default:
                 return ORC_CORRUPTED;      /* the degenerate filler symbol 19 */
@@ -334,8 +348,8 @@ static int read_prefix_codes(bitrd *br, tables *t) {
  *   *out_off       <- flate.Reader.OutputOffset (bytes delivered)
  * returns ORC_*.
  */
-int oracle_inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
-                   int64_t *in_off, int64_t *out_off)
+int oracle_inflate_ex(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                      int64_t *in_off, int64_t *out_off, int rfc_rep16)
 {
     static __thread tables t;     /* large; keep off the stack, one per thread */
     if (!t.fixed_ready) init_fixed(&t);
@@ -383,7 +397,7 @@ int oracle_inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_ca
             lit_tree = &t.fixed_lit; dist_tree = &t.fixed_dist;
             break;
         case 2:
-            status = read_prefix_codes(&br, &t);
+            status = read_prefix_codes(&br, &t, rfc_rep16);
             if (status != ORC_OK) goto done;
             lit_tree = &t.lit; dist_tree = &t.dist;
             break;
@@ -437,6 +451,13 @@ done:
     return status;
 }
 
+/* The flate.Reader path (in-repo flate package semantics). */
+int oracle_inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                   int64_t *in_off, int64_t *out_off)
+{
+    return oracle_inflate_ex(in, in_len, out, out_cap, in_off, out_off, 0);
+}
+
 /*
  * xflate.Reader's view of one chunk (xflate/reader.go:32-70,186-202): the
  * decompressor sees `chunk || 01 00 00 ff ff`.  tmp must hold comp_len + 5.
@@ -447,7 +468,8 @@ int oracle_inflate_chunk(const uint8_t *comp, size_t comp_len, uint8_t *tmp,
     static const uint8_t end_block[5] = {0x01, 0x00, 0x00, 0xff, 0xff};   /* xflate/common.go:57 */
     memcpy(tmp, comp, comp_len);
     memcpy(tmp + comp_len, end_block, 5);
-    return oracle_inflate(tmp, comp_len + 5, out, out_cap, in_off, out_off);
+    /* stdlib compress/flate is the inflater on this path: RFC rule for symbol 16 */
+    return oracle_inflate_ex(tmp, comp_len + 5, out, out_cap, in_off, out_off, 1);
 }
 
 /*
