@@ -1,0 +1,161 @@
+"""ctypes binding of include/xflate_amd.h.  Fails loudly if libxflate_amd.so is missing."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libxflate_amd.so")
+
+# transport codes
+XFG_OK, XFG_E_ARG, XFG_E_HIP, XFG_E_NODEVICE, XFG_E_NOMEM, XFG_E_LIMIT = range(6)
+# per-chunk status
+ST_OK, ST_CORRUPTED, ST_UNEXPECTED_EOF, ST_SIZE_MISMATCH, ST_NO_SYNC, ST_INTERNAL, ST_OUT_FULL = range(7)
+ST_NAMES = ["ok", "corrupted", "unexpected_eof", "size_mismatch", "no_sync", "internal", "out_full"]
+# chunk flags
+CHUNK_END_BLOCK, CHUNK_SYNC, CHUNK_VERIFY, CHUNK_FOOTER, CHUNK_RFC_REP16 = 1, 2, 4, 8, 16
+CHUNK_XFLATE_DEFLATE = CHUNK_END_BLOCK | CHUNK_SYNC | CHUNK_VERIFY | CHUNK_RFC_REP16
+CHUNK_XFLATE_INDEX = CHUNK_END_BLOCK | CHUNK_VERIFY | CHUNK_RFC_REP16
+CHUNK_XFLATE_FOOTER = CHUNK_END_BLOCK | CHUNK_VERIFY | CHUNK_FOOTER | CHUNK_RFC_REP16
+# error classes
+ERR_NONE, ERR_INTERNAL, ERR_INVALID, ERR_DEPRECATED, ERR_CORRUPTED, ERR_CLOSED = range(6)
+ERR_EOF, ERR_UNEXPECTED_EOF, ERR_IO, ERR_DEVICE = 16, 17, 18, 19
+REC_UNKNOWN, REC_DEFLATE, REC_INDEX, REC_FOOTER = range(4)
+
+
+class Chunk(ctypes.Structure):
+    _fields_ = [("comp_off", ctypes.c_uint64), ("comp_size", ctypes.c_uint64),
+                ("raw_off", ctypes.c_uint64), ("raw_size", ctypes.c_uint64),
+                ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("reserved", ctypes.c_uint32),
+                ("in_consumed", ctypes.c_int64), ("out_produced", ctypes.c_int64)]
+
+
+class Record(ctypes.Structure):
+    _fields_ = [("comp_offset", ctypes.c_int64), ("raw_offset", ctypes.c_int64),
+                ("type", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+READ_FN = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int64)
+SEEK_FN = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int)
+
+# every symbol include/xflate_amd.h declares
+SYMBOLS = [
+    "xfg_device_count", "xfg_create", "xfg_destroy", "xfg_strerror", "xfg_last_error",
+    "xfg_decode", "xfg_decode_device", "xfg_sync",
+    "xfg_reader_new", "xfg_reader_reset", "xfg_reader_read", "xfg_reader_seek", "xfg_reader_close",
+    "xfg_reader_free", "xfg_reader_num_records", "xfg_reader_get_records", "xfg_reader_bytes_read",
+    "xfg_reader_set_window", "xfg_index_parse", "xfg_flate_decode",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libxflate_amd.so (built by __graft_entry__.build() / make -C compress_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libxflate_amd.so not built: run `make -C compress_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, i64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64
+    L.xfg_device_count.restype = ctypes.c_int
+    L.xfg_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.xfg_destroy.argtypes = [vp]
+    L.xfg_destroy.restype = None
+    L.xfg_strerror.argtypes = [ctypes.c_int]
+    L.xfg_strerror.restype = ctypes.c_char_p
+    L.xfg_last_error.restype = ctypes.c_char_p
+    L.xfg_decode.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
+    L.xfg_decode_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    L.xfg_sync.argtypes = [vp]
+    L.xfg_reader_new.argtypes = [vp, READ_FN, SEEK_FN, vp, ctypes.POINTER(vp)]
+    L.xfg_reader_reset.argtypes = [vp, READ_FN, SEEK_FN, vp]
+    L.xfg_reader_read.argtypes = [vp, vp, i64, ctypes.POINTER(ctypes.c_int)]
+    L.xfg_reader_read.restype = i64
+    L.xfg_reader_seek.argtypes = [vp, i64, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.xfg_reader_seek.restype = i64
+    L.xfg_reader_close.argtypes = [vp]
+    L.xfg_reader_free.argtypes = [vp]
+    L.xfg_reader_free.restype = None
+    L.xfg_reader_num_records.argtypes = [vp]
+    L.xfg_reader_num_records.restype = i64
+    L.xfg_reader_get_records.argtypes = [vp, vp, i64]
+    L.xfg_reader_bytes_read.argtypes = [vp]
+    L.xfg_reader_bytes_read.restype = i64
+    L.xfg_reader_set_window.argtypes = [vp, i64]
+    L.xfg_index_parse.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
+    L.xfg_flate_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(i64), ctypes.POINTER(i64),
+                                   ctypes.POINTER(ctypes.c_int)]
+    _lib = L
+    return L
+
+
+class TransportError(RuntimeError):
+    pass
+
+
+def check(rc, what="xfg call"):
+    if rc != XFG_OK:
+        L = lib()
+        raise TransportError("%s failed: %s (%s)" % (what, L.xfg_strerror(rc).decode(), L.xfg_last_error().decode()))
+
+
+class Context:
+    """One device context (xfg_create/xfg_destroy)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        check(lib().xfg_create(device, ctypes.byref(self._h)), "xfg_create(%d)" % device)
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().xfg_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib().xfg_sync(self._h), "xfg_sync")
+
+    def decode(self, comp, chunks, raw_len):
+        """Host-pointer batch decode.  chunks: list of (comp_off, comp_size, raw_off, raw_size, flags).
+        -> (raw bytearray, [Result...])"""
+        n = len(chunks)
+        arr = (Chunk * max(n, 1))()
+        for i, c in enumerate(chunks):
+            arr[i] = Chunk(c[0], c[1], c[2], c[3], c[4], 0)
+        res = (Result * max(n, 1))()
+        comp = bytes(comp)
+        raw = ctypes.create_string_buffer(max(raw_len, 1))
+        check(lib().xfg_decode(self._h, comp, len(comp), arr, n, raw, raw_len, res), "xfg_decode")
+        return raw, [res[i] for i in range(n)]
+
+    def decode_device(self, d_comp, comp_len, d_chunks, n, d_raw, raw_len, d_res, stream=None):
+        """Device-pointer batch decode (async).  Pointers are ints (e.g. torch tensor .data_ptr())."""
+        check(lib().xfg_decode_device(self._h, d_comp, comp_len, d_chunks, n, d_raw, raw_len, d_res,
+                                      stream or None), "xfg_decode_device")
+
+
+def index_parse(stream):
+    """xfg_index_parse: -> (err class, [Chunk...]) for every record of an in-memory XFLATE stream."""
+    stream = bytes(stream)
+    n = ctypes.c_size_t()
+    err = lib().xfg_index_parse(stream, len(stream), None, 0, ctypes.byref(n))
+    if err != ERR_NONE:
+        return err, []
+    arr = (Chunk * max(n.value, 1))()
+    err = lib().xfg_index_parse(stream, len(stream), arr, n.value, ctypes.byref(n))
+    return err, [arr[i] for i in range(n.value)]

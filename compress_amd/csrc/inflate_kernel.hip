@@ -1,0 +1,647 @@
+// inflate_kernel.hip -- DEFLATE inflate of independent XFLATE chunks on gfx950.
+//
+// One wavefront owns one chunk.  A workgroup
+// is 4 independent waves; they share nothing and never barrier.
+//
+// What this restates, in the reference's terms (all under /root/reference):
+//   chunkReader            xflate/reader.go:32-70      -> win_load(): chunk || 01 00 00 ff ff is a virtual stream
+//   readBlockHeader        flate/reader.go:100-134     -> the block loop of inflate_chunk()
+//   readRawData            flate/reader.go:137-159     -> stored_copy()
+//   ReadPrefixCodes        flate/prefix.go:83-194      -> read_dynamic_header()
+//   GeneratePrefixes       internal/prefix/prefix.go:326-384 -> build_table() steps 1-3 (histogram, Kraft, canonical rank)
+//   Decoder.Init           internal/prefix/decoder.go:51-136 -> build_table() steps 4-5 (root table + sub-tables in LDS)
+//   readBlock              flate/reader.go:162-250     -> decode_block()
+//   dictDecoder            flate/dict_decoder.go:86-132 -> match_copy(): the output buffer is the window
+//   Read's post-chunk checks xflate/reader.go:186-202  -> epilogue of inflate_chunk()
+//
+// The decode state (bit buffer, positions, table entries) is wave-uniform and
+// kept in SGPRs via readfirstlane; the 64 lanes cooperate on everything that
+// has width: coalesced refill of the compressed window into LDS, table
+// construction, stored-block and match copies.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/xflate_amd.h"
+
+namespace xfg {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int LIT_ROOT = 10;            // first-level bits, literal/length table
+constexpr int DIST_ROOT = 8;            // first-level bits, distance table
+constexpr int CLEN_ROOT = 7;            // code-length code: max length 7, never needs sub-tables
+constexpr int LIT_TAB = 1344;           // >= enough(286, 10, 15) = 1334 entries
+constexpr int DIST_TAB = 416;           // >= enough(30, 8, 15)  = 402 entries
+constexpr int CLEN_TAB = 128;
+constexpr int WIN_BYTES = 1024;         // compressed-stream window: two 512-byte halves
+constexpr int MAX_HIST = 32768;         // flate/common.go:16
+
+// Table entry (u32):
+//   [4:0]   bits to consume for this code word (total code length, sub-table entries included)
+//   [7:5]   kind
+//   [12:8]  number of extra bits (length / distance) or sub-table index bits (K_SUB)
+//   [31:16] literal byte, length base, distance base, code-length symbol, or sub-table offset
+enum : u32 { K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SUB = 3, K_INVALID = 4 };
+enum : int { T_LIT = 0, T_DIST = 1, T_CLEN = 2 };
+
+__device__ __forceinline__ u32 mk_entry(u32 nbits, u32 kind, u32 extra, u32 val) {
+    return nbits | (kind << 5) | (extra << 8) | (val << 16);
+}
+__device__ __forceinline__ u32 e_nbits(u32 e) { return e & 31; }
+__device__ __forceinline__ u32 e_kind(u32 e) { return (e >> 5) & 7; }
+__device__ __forceinline__ u32 e_extra(u32 e) { return (e >> 8) & 31; }
+__device__ __forceinline__ u32 e_val(u32 e) { return e >> 16; }
+
+// Symbol -> entry.  lenRanges / distRanges of flate/prefix.go:23-32 in closed form.
+__device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
+    if (type == T_LIT) {
+        if (sym < 256) return mk_entry(nbits, K_LIT, 0, sym);
+        if (sym == 256) return mk_entry(nbits, K_EOB, 0, 0);
+        if (sym >= 286) return mk_entry(nbits, K_INVALID, 0, 0);      // flate/reader.go:228-229
+        u32 s = sym - 257;
+        if (s < 8) return mk_entry(nbits, K_BASE, 0, 3 + s);
+        if (s == 28) return mk_entry(nbits, K_BASE, 0, 258);
+        u32 e = (s - 4) >> 2;
+        return mk_entry(nbits, K_BASE, e, 3 + ((4 + (s & 3)) << e));
+    } else if (type == T_DIST) {
+        if (sym >= 30) return mk_entry(nbits, K_INVALID, 0, 0);       // flate/reader.go:212-214
+        if (sym < 4) return mk_entry(nbits, K_BASE, 0, 1 + sym);
+        u32 e = (sym - 2) >> 1;
+        return mk_entry(nbits, K_BASE, e, 1 + ((2 + (sym & 1)) << e));
+    } else {
+        if (sym >= 19) return mk_entry(nbits, K_INVALID, 0, 0);       // flate/prefix.go:150-152
+        return mk_entry(nbits, K_LIT, 0, sym);
+    }
+}
+
+// Per-wave LDS.  ~9.6 KiB -> 16 waves per CU.
+struct WaveLds {
+    u32 lit[LIT_TAB];
+    u32 dist[DIST_TAB];
+    u32 clen[CLEN_TAB];
+    u64 win[WIN_BYTES / 8];
+    u16 sorted[320];        // symbols in canonical (length, symbol) order
+    u8  lens[320];          // code lengths: [0,hlit) literal/length, [hlit, hlit+hdist) distance
+    u8  clens[32];          // code lengths of the code-length code
+    u32 cnt[16];            // histogram of code lengths
+    u32 first[16];          // first canonical code of each length
+    u32 offs[16];           // index in sorted[] of the first symbol of each length
+    u32 endr[16];           // end of the length-l codes in ROOT-bit code space (l <= ROOT)
+};
+
+__device__ __forceinline__ void wave_sync() {
+    // LDS operations of one wave execute in order; this only stops the compiler
+    // from moving LDS accesses across the point where lanes exchange data.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ u32 uni(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u64 uni64(u64 v) {
+    u32 lo = __builtin_amdgcn_readfirstlane((u32)v);
+    u32 hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------
+// Bit reader over the virtual stream chunk || endBlock, wave-uniform.
+// ---------------------------------------------------------------------------
+struct Reader {
+    const u8 *comp;     // whole compressed buffer
+    u64 base_al;        // comp_off rounded down to 512
+    u32 lead;           // comp_off - base_al
+    u32 csize;          // chunk bytes
+    u32 total;          // csize + 5 if the endBlock is appended
+    u32 bytepos;        // next stream byte to feed into bitbuf
+    i32 blk_hi;         // highest 512-byte window block resident (blk_hi-1 and blk_hi are in LDS)
+    u64 bitbuf;
+    u32 bitcnt;
+    u64 *win;
+    u32 lane;
+};
+
+__device__ __forceinline__ void win_load(Reader &r, i32 k) {
+    // Block k covers window positions [512k, 512k+512); window position q = lead + stream byte index.
+    const u32 q0 = (u32)k * 512u + r.lane * 8u;
+    const i64 ci = (i64)q0 - (i64)r.lead;                 // stream byte index of this lane's first byte
+    u64 w;
+    if (ci + 8 <= (i64)r.csize) {
+        // Entirely at or before the chunk's last byte: one aligned 8-byte load.  Bytes
+        // before the chunk start (ci < 0) belong to the previous chunk and are never consumed.
+        w = *reinterpret_cast<const u64 *>(r.comp + r.base_al + q0);
+    } else {
+        // Tail: chunk bytes, then 01 00 00 ff ff (xflate/common.go:57), then zeros.
+        w = 0;
+        for (int j = 0; j < 8; j++) {
+            const i64 idx = ci + j;
+            u32 b = 0;
+            if (idx >= 0) {
+                if (idx < (i64)r.csize) b = r.comp[r.base_al + q0 + j];
+                else if (idx < (i64)r.total) {
+                    const u32 t = (u32)(idx - r.csize);       // 0..4
+                    b = (t == 0) ? 0x01u : (t >= 3 ? 0xffu : 0x00u);
+                }
+            }
+            w |= (u64)b << (8 * j);
+        }
+    }
+    r.win[(k & 1) * 64 + r.lane] = w;
+}
+
+// Make sure the 8 bytes at stream position bytepos are in the window.
+__device__ __forceinline__ void win_ensure(Reader &r) {
+    const u32 q = r.bytepos + r.lead;
+    const i32 need = (i32)((q + 7) >> 9);
+    if (need > r.blk_hi) {
+        if (need > r.blk_hi + 1) r.blk_hi = (i32)(q >> 9) - 1;     // jumped (after a stored block)
+        while (r.blk_hi < need) {
+            r.blk_hi++;
+            win_load(r, r.blk_hi);
+        }
+        wave_sync();
+    }
+}
+
+// Top up the bit buffer to >= 56 bits.  Bytes past the end of the stream read as zero;
+// avail() tells how many of the buffered bits are real.
+__device__ __forceinline__ void refill(Reader &r) {
+    win_ensure(r);
+    const u32 q = (r.bytepos + r.lead) & (WIN_BYTES - 1);
+    const u32 i0 = q >> 3;
+    const u64 lo = r.win[i0];
+    const u64 hi = r.win[(i0 + 1) & (WIN_BYTES / 8 - 1)];
+    const u32 sh = (q & 7) * 8;
+    u64 v = lo >> sh;
+    if (sh) v |= hi << (64 - sh);
+    v = uni64(v);
+    r.bitbuf |= v << r.bitcnt;
+    r.bytepos += (63 - r.bitcnt) >> 3;
+    r.bitcnt |= 56;
+}
+__device__ __forceinline__ i32 avail(const Reader &r) {
+    return ((i32)r.total - (i32)r.bytepos) * 8 + (i32)r.bitcnt;
+}
+__device__ __forceinline__ void consume(Reader &r, u32 n) {
+    r.bitbuf >>= n;
+    r.bitcnt -= n;
+}
+__device__ __forceinline__ u32 peek(const Reader &r, u32 n) {
+    return (u32)r.bitbuf & ((1u << n) - 1);
+}
+// InputOffset = ceil(consumed bits / 8)  (internal/prefix/reader.go:226-245)
+__device__ __forceinline__ i64 in_offset(const Reader &r) {
+    const i64 consumed = (i64)r.bytepos * 8 - (i64)r.bitcnt;
+    return (consumed + 7) >> 3;
+}
+
+// ---------------------------------------------------------------------------
+// Canonical prefix-code table construction, wave-cooperative, directly in LDS.
+// Returns 0 = ok, 1 = empty code (decode with it is an error), 2 = invalid
+// (over/under-subscribed: GeneratePrefixes errors, prefix.go:355-369).
+// ---------------------------------------------------------------------------
+template <int TYPE, int ROOT>
+__device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane) {
+    // 1. histogram of code lengths
+    if (lane < 16) L.cnt[lane] = 0;
+    wave_sync();
+    for (u32 i = lane; i < n; i += 64) {
+        const u32 l = lens[i];
+        if (l) atomicAdd(&L.cnt[l], 1u);
+    }
+    wave_sync();
+
+    // 2. Kraft check and canonical first codes (uniform; every lane computes the same)
+    u32 cnt[16];
+    u32 nz = 0, maxlen = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) {
+        cnt[l] = uni(L.cnt[l]);
+        nz += cnt[l];
+        if (cnt[l]) maxlen = l;
+    }
+    if (nz == 0) return 1;
+    bool degenerate = false;
+    if (nz == 1) {
+        // handleDegenerateCodes (flate/prefix.go:203-208): a lone 1-bit code gets a
+        // sibling whose symbol is out of range; any other lone code is incomplete.
+        if (cnt[1] != 1) return 2;
+        degenerate = true;
+        cnt[1] = 2;
+    }
+    {
+        i32 left = 1;
+#pragma unroll
+        for (int l = 1; l <= 15; l++) {
+            left = left * 2 - (i32)cnt[l];
+            if (left < 0) return 2;
+        }
+        if (left != 0) return 2;
+    }
+    u32 run[16];
+    {
+        u32 code = 0, off = 0;
+#pragma unroll
+        for (int l = 1; l <= 15; l++) {
+            code <<= 1;
+            run[l] = off;
+            if (lane == 0) {
+                L.first[l] = code;
+                L.offs[l] = off;
+                L.cnt[l] = cnt[l];
+                if (l <= ROOT) L.endr[l] = (code + cnt[l]) << (ROOT - l);
+            }
+            code += cnt[l];
+            off += cnt[l];
+        }
+    }
+
+    // 3. canonical order: sorted[offs[len] + rank within len] = symbol
+    for (u32 base = 0; base < n; base += 64) {
+        const u32 i = base + lane;
+        const u32 l = (i < n) ? lens[i] : 0;
+#pragma unroll
+        for (int q = 1; q <= 15; q++) {
+            if (cnt[q] == 0) continue;
+            const u64 m = __ballot(l == (u32)q);
+            if (l == (u32)q) L.sorted[run[q] + __popcll(m & ((1ull << lane) - 1))] = (u16)i;
+            run[q] += __popcll(m);
+        }
+    }
+    if (degenerate && lane == 0) L.sorted[1] = 0xffff;          // the out-of-range sibling
+    wave_sync();
+
+    // 4. root table.  u runs over ROOT-bit code space MSB-first; the table is indexed LSB-first.
+    //    Codes of length l <= ROOT own [endr[l-1], endr[l]) there; whatever lies at or beyond
+    //    end_root is the prefix of a longer code.
+    const u32 lim = maxlen < (u32)ROOT ? maxlen : (u32)ROOT;
+    const u32 end_root = uni(L.endr[lim]);
+    for (u32 u = lane; u < end_root; u += 64) {
+        u32 l = 1;
+        while (u >= L.endr[l]) l++;
+        const u32 sym = L.sorted[L.offs[l] + (u >> (ROOT - l)) - L.first[l]];
+        tab[__brev(u) >> (32 - ROOT)] = sym_entry(TYPE, sym, l);
+    }
+
+    // 5. sub-tables for code words longer than ROOT: one per ROOT-bit prefix u >= end_root,
+    //    sized by the longest code under that prefix (as zlib's inftrees does).
+    if (maxlen > (u32)ROOT) {
+        u32 next = 1u << ROOT;                                  // running sub-table offset (uniform)
+        for (u32 ub = end_root; ub < (1u << ROOT); ub += 64) {
+            const u32 u = ub + lane;
+            const bool act = u < (1u << ROOT);
+            u32 sb = 0;
+            if (act) {
+                for (u32 l = maxlen; l > (u32)ROOT; l--) {
+                    const u32 c = L.cnt[l];
+                    if (!c) continue;
+                    const u32 f = L.first[l];
+                    const u32 lo = u << (l - ROOT), hi = (u + 1) << (l - ROOT);
+                    if (lo < f + c && hi > f) { sb = l - ROOT; break; }
+                }
+            }
+            // exclusive scan of sub-table sizes over the wave
+            const u32 size = act ? (1u << sb) : 0;
+            u32 incl = size;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 t = __shfl_up(incl, d);
+                if (lane >= (u32)d) incl += t;
+            }
+            const u32 my_off = next + incl - size;
+            next += uni(__shfl(incl, 63));
+            if (act) {
+                tab[__brev(u) >> (32 - ROOT)] = mk_entry(0, K_SUB, sb, my_off);
+                for (u32 v = 0; v < (1u << sb); v++) {
+                    const u32 w = (u << sb) | v;                // (ROOT+sb)-bit code space, MSB-first
+                    u32 l = ROOT + 1;
+                    while (l < ROOT + sb && (w >> (ROOT + sb - l)) >= L.first[l] + L.cnt[l]) l++;
+                    const u32 sym = L.sorted[L.offs[l] + (w >> (ROOT + sb - l)) - L.first[l]];
+                    tab[my_off + (__brev(v) >> (32 - sb))] = sym_entry(TYPE, sym, l);
+                }
+            }
+        }
+    }
+    wave_sync();
+    return 0;
+}
+
+// Table lookup at the head of the bit buffer (TryReadSymbol/ReadSymbol, prefix/reader.go:183-221).
+template <int ROOT>
+__device__ __forceinline__ u32 lookup(const u32 *tab, u64 bitbuf) {
+    u32 e = uni(tab[(u32)bitbuf & ((1u << ROOT) - 1)]);
+    if (e_kind(e) == K_SUB)
+        e = uni(tab[e_val(e) + (((u32)(bitbuf >> ROOT)) & ((1u << e_extra(e)) - 1))]);
+    return e;
+}
+
+struct Out {
+    u8 *raw;            // this chunk's output
+    u32 cap;            // raw_size
+    u32 pos;            // bytes produced
+    u32 acked;          // every byte below this index is known to be visible to loads
+};
+
+__device__ __forceinline__ void make_visible(Out &o) {
+    // Stores of this wave reach L2 through the CU's own write-through L1; waiting for
+    // them (workgroup-scope release) is all a later load from the same CU needs.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    o.acked = o.pos;
+}
+
+// dictDecoder.TryWriteCopy/WriteCopy (flate/dict_decoder.go:86-132): forward copy with
+// byte-serial overlap semantics == periodic fill from the dist bytes before pos.
+__device__ __forceinline__ void match_copy(Out &o, u32 len, u32 dist, u32 lane) {
+    const u32 src = o.pos - dist;
+    const u32 src_end = dist >= len ? src + len : o.pos;
+    if (src_end > o.acked) make_visible(o);
+    if (dist >= len) {
+        for (u32 k = lane; k < len; k += 64) o.raw[o.pos + k] = o.raw[src + k];
+    } else if (dist == 1) {
+        const u8 b = o.raw[src];
+        for (u32 k = lane; k < len; k += 64) o.raw[o.pos + k] = b;
+    } else {
+        const u32 m = 0xffffffffu / dist + 1;                   // exact k / dist for k < 65536
+        for (u32 k = lane; k < len; k += 64) {
+            const u32 qk = __umulhi(k, m);
+            o.raw[o.pos + k] = o.raw[src + (k - qk * dist)];
+        }
+    }
+    o.pos += len;
+}
+
+// readRawData (flate/reader.go:137-159): n bytes from stream position sp to the output.
+__device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32 n, u32 lane) {
+    const u8 *src = r.comp + r.base_al + r.lead;
+    for (u32 k = lane; k < n; k += 64) {
+        const u32 idx = sp + k;
+        u8 b;
+        if (idx < r.csize) b = src[idx];
+        else { const u32 t = idx - r.csize; b = (t == 0) ? 0x01 : (t >= 3 ? 0xff : 0x00); }
+        o.raw[o.pos + k] = b;
+    }
+    o.pos += n;
+}
+
+// ReadPrefixCodes (flate/prefix.go:83-194).  Returns an XFG_ST_* status.
+__device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep16, int &lit_state, int &dist_state) {
+    refill(r);
+    // three ReadBits; each one either gets all its bits or fails consuming none
+    if (avail(r) < 5) return XFG_ST_UNEXPECTED_EOF;
+    const u32 hlit = peek(r, 5) + 257;  consume(r, 5);
+    if (avail(r) < 5) return XFG_ST_UNEXPECTED_EOF;
+    const u32 hdist = peek(r, 5) + 1;   consume(r, 5);
+    if (avail(r) < 4) return XFG_ST_UNEXPECTED_EOF;
+    const u32 hclen = peek(r, 4) + 4;   consume(r, 4);
+    if (hlit > 286 || hdist > 30) return XFG_ST_CORRUPTED;      // prefix.go:87-89
+
+    // code-length code lengths, 3 bits each, in clenLens order (prefix.go:67,92-98)
+    if (lane < 19) L.clens[lane] = 0;
+    wave_sync();
+    for (u32 i = 0; i < hclen; i++) {
+        if (r.bitcnt < 3) refill(r);
+        if (avail(r) < 3) return XFG_ST_UNEXPECTED_EOF;
+        const u32 v = peek(r, 3);
+        consume(r, 3);
+        // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
+        u32 s;
+        if (i < 3) s = 16 + i;
+        else if (i == 3) s = 0;
+        else if ((i & 1) == 0) s = 8 + ((i - 4) >> 1);          // i=4,6,8,..,18 -> 8,9,10,..,15
+        else s = 7 - ((i - 5) >> 1);                            // i=5,7,9,..,17 -> 7,6,5,..,1
+        if (lane == 0) L.clens[s] = (u8)v;
+    }
+    wave_sync();
+    const int cst = build_table<T_CLEN, CLEN_ROOT>(L, L.clen, L.clens, 19, lane);
+    if (cst == 2) return XFG_ST_CORRUPTED;
+
+    // literal/length and distance code lengths with the 16/17/18 repeaters (prefix.go:125-165)
+    const u32 max_syms = hlit + hdist;
+    u32 prev = 0;                                               // clenLast
+    for (u32 sym = 0; sym < max_syms;) {
+        if (cst == 1) return XFG_ST_CORRUPTED;                  // "decode with empty prefix tree"
+        if (r.bitcnt < 32) refill(r);
+        const u32 e = lookup<CLEN_ROOT>(L.clen, r.bitbuf);
+        if ((i32)e_nbits(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
+        consume(r, e_nbits(e));
+        if (e_kind(e) == K_INVALID) return XFG_ST_CORRUPTED;    // the degenerate filler symbol
+        const u32 c = e_val(e);
+        if (c < 16) {
+            if (lane == 0) L.lens[sym] = (u8)c;
+            prev = c;
+            sym++;
+            continue;
+        }
+        u32 val, rep, nb;
+        if (c == 16) {
+            if (sym == 0) return XFG_ST_CORRUPTED;              // prefix.go:139-141
+            val = prev; nb = 2; rep = 3;
+        } else if (c == 17) { val = 0; nb = 3; rep = 3; }
+        else { val = 0; nb = 7; rep = 11; }
+        if ((i32)nb > avail(r)) return XFG_ST_UNEXPECTED_EOF;
+        rep += peek(r, nb);
+        consume(r, nb);
+        if (c != 16 && rfc_rep16) prev = 0;                     // stdlib: 16 repeats the previous array entry
+        const u32 end = sym + rep;
+        for (u32 k = sym + lane; k < end && k < max_syms; k += 64) L.lens[k] = (u8)val;
+        sym = end;
+        if (sym > max_syms) return XFG_ST_CORRUPTED;            // prefix.go:161-163
+    }
+    wave_sync();
+    // lens[0 .. hlit) literal/length, lens[hlit .. hlit+hdist) distance
+    lit_state = build_table<T_LIT, LIT_ROOT>(L, L.lit, L.lens, hlit, lane);
+    if (lit_state == 2) return XFG_ST_CORRUPTED;
+    dist_state = build_table<T_DIST, DIST_ROOT>(L, L.dist, L.lens + hlit, hdist, lane);
+    if (dist_state == 2) return XFG_ST_CORRUPTED;
+    return XFG_ST_OK;
+}
+
+// Fixed code sets of RFC 1951 3.2.6 (flate/prefix.go:35-63).
+__device__ void build_fixed(WaveLds &L, u32 lane) {
+    for (u32 i = lane; i < 288; i += 64)
+        L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+    wave_sync();
+    build_table<T_LIT, LIT_ROOT>(L, L.lit, L.lens, 288, lane);
+    if (lane < 32) L.clens[lane] = 5;
+    wave_sync();
+    build_table<T_DIST, DIST_ROOT>(L, L.dist, L.clens, 32, lane);
+}
+
+// readBlock (flate/reader.go:162-250).  Returns XFG_ST_OK at the end-of-block symbol.
+__device__ int decode_block(Reader &r, Out &o, WaveLds &L, u32 lane, int lit_state, int dist_state) {
+    for (;;) {
+        if (lit_state == 1) return XFG_ST_CORRUPTED;            // empty literal tree: prefix/reader.go:199-201
+        refill(r);
+        u32 e = lookup<LIT_ROOT>(L.lit, r.bitbuf);
+        if ((i32)e_nbits(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
+        consume(r, e_nbits(e));
+        const u32 kind = e_kind(e);
+        if (kind == K_LIT) {
+            if (o.pos >= o.cap) return XFG_ST_OUT_FULL;
+            if (lane == 0) o.raw[o.pos] = (u8)e_val(e);
+            o.pos++;
+            continue;
+        }
+        if (kind == K_EOB) return XFG_ST_OK;
+        if (kind != K_BASE) return XFG_ST_CORRUPTED;            // symbols 286/287 or the degenerate filler
+        u32 xb = e_extra(e);
+        if ((i32)xb > avail(r)) return XFG_ST_UNEXPECTED_EOF;
+        const u32 len = e_val(e) + peek(r, xb);
+        consume(r, xb);
+        // distance symbol
+        if (dist_state == 1) return XFG_ST_CORRUPTED;
+        e = lookup<DIST_ROOT>(L.dist, r.bitbuf);
+        if ((i32)e_nbits(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
+        consume(r, e_nbits(e));
+        if (e_kind(e) != K_BASE) return XFG_ST_CORRUPTED;
+        xb = e_extra(e);
+        if ((i32)xb > avail(r)) return XFG_ST_UNEXPECTED_EOF;
+        const u32 dist = e_val(e) + peek(r, xb);
+        consume(r, xb);
+        const u32 hist = o.pos < (u32)MAX_HIST ? o.pos : (u32)MAX_HIST;     // dictDecoder.HistSize
+        if (dist > hist) return XFG_ST_CORRUPTED;               // flate/reader.go:223-225
+        if (len > o.cap - o.pos) {
+            match_copy(o, o.cap - o.pos, dist, lane);           // keep what fits, then report
+            return XFG_ST_OUT_FULL;
+        }
+        match_copy(o, len, dist, lane);
+    }
+}
+
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
+inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
+                      u8 *__restrict__ raw, xfg_result *__restrict__ res)
+{
+    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+    const u32 wave = uni(threadIdx.x >> 6);
+    const u32 lane = threadIdx.x & 63;
+    const u32 ci = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (ci >= n) return;
+    WaveLds &L = lds[wave];
+    xfg_chunk c = chunks[ci];
+    c.comp_off = uni64(c.comp_off);
+    c.raw_off = uni64(c.raw_off);
+    const u32 flags = uni(c.flags);
+
+    Reader r;
+    r.comp = comp;
+    r.base_al = c.comp_off & ~(u64)511;
+    r.lead = uni((u32)(c.comp_off & 511));
+    r.csize = uni((u32)c.comp_size);
+    r.total = r.csize + ((flags & XFG_CHUNK_END_BLOCK) ? 5u : 0u);
+    r.bytepos = 0;
+    r.blk_hi = -1;
+    r.bitbuf = 0;
+    r.bitcnt = 0;
+    r.win = L.win;
+    r.lane = lane;
+
+    Out o;
+    o.raw = raw + c.raw_off;
+    o.cap = uni((u32)c.raw_size);
+    o.pos = 0;
+    o.acked = 0;
+
+    const bool rfc_rep16 = (flags & XFG_CHUNK_RFC_REP16) != 0;
+    int status;
+    int tables = 0;                                             // 0 none, 1 fixed, 2 dynamic
+
+    for (;;) {
+        // readBlockHeader (flate/reader.go:100-134)
+        refill(r);
+        if (avail(r) < 1) { status = XFG_ST_UNEXPECTED_EOF; break; }
+        const u32 last = peek(r, 1);
+        consume(r, 1);
+        if (avail(r) < 2) { status = XFG_ST_UNEXPECTED_EOF; break; }
+        const u32 btype = peek(r, 2);
+        consume(r, 2);
+        if (btype == 0) {
+            consume(r, r.bitcnt & 7);                           // ReadPads
+            if (avail(r) < 16) { status = XFG_ST_UNEXPECTED_EOF; break; }
+            const u32 len = peek(r, 16);
+            consume(r, 16);
+            if (avail(r) < 16) { status = XFG_ST_UNEXPECTED_EOF; break; }
+            const u32 nlen = peek(r, 16);
+            consume(r, 16);
+            if ((len ^ nlen) != 0xffff) { status = XFG_ST_CORRUPTED; break; }
+            // stream position of the first data byte; drop the look-ahead bits
+            const u32 sp = r.bytepos - (r.bitcnt >> 3);
+            u32 take = len;
+            bool eof = false, full = false;
+            if (take > r.total - sp) { take = r.total - sp; eof = true; }
+            if (take > o.cap - o.pos) { take = o.cap - o.pos; full = true; eof = false; }
+            stored_copy(r, o, sp, take, lane);
+            r.bytepos = sp + take;
+            r.bitbuf = 0;
+            r.bitcnt = 0;
+            if (full) { status = XFG_ST_OUT_FULL; break; }
+            if (eof) { status = XFG_ST_UNEXPECTED_EOF; break; }
+        } else if (btype == 3) {
+            status = XFG_ST_CORRUPTED;                          // reserved block type
+            break;
+        } else {
+            int lit_state = 0, dist_state = 0;
+            if (btype == 1) {
+                if (tables != 1) build_fixed(L, lane);
+                tables = 1;
+            } else {
+                tables = 2;
+                status = read_dynamic_header(r, L, lane, rfc_rep16, lit_state, dist_state);
+                if (status != XFG_ST_OK) break;
+            }
+            status = decode_block(r, o, L, lane, lit_state, dist_state);
+            if (status != XFG_ST_OK) break;
+        }
+        // finishBlock (flate/reader.go:253-259)
+        if (last) {
+            consume(r, r.bitcnt & 7);                           // ReadPads
+            status = XFG_ST_OK;
+            break;
+        }
+    }
+
+    const i64 in_off = in_offset(r);
+    // xflate.Reader's checks after a chunk's io.EOF (xflate/reader.go:186-202)
+    if (status == XFG_ST_OK) {
+        if (flags & XFG_CHUNK_SYNC) {
+            bool ok = r.csize >= 4;
+            if (ok) {
+                const u8 *p = comp + c.comp_off + r.csize - 4;
+                ok = p[0] == 0x00 && p[1] == 0x00 && p[2] == 0xff && p[3] == 0xff;
+            }
+            if (!ok) status = XFG_ST_NO_SYNC;
+        }
+        if (status == XFG_ST_OK && (flags & XFG_CHUNK_VERIFY)) {
+            const i64 want_in = (i64)r.csize + ((flags & XFG_CHUNK_FOOTER) ? 0 : ((flags & XFG_CHUNK_END_BLOCK) ? 5 : 0));
+            if (in_off != want_in || o.pos != o.cap) status = XFG_ST_SIZE_MISMATCH;
+        }
+    } else if (status == XFG_ST_OUT_FULL && (flags & XFG_CHUNK_VERIFY)) {
+        status = XFG_ST_SIZE_MISMATCH;                          // more output than the index promised
+    }
+    if (lane == 0) {
+        xfg_result out;
+        out.status = status;
+        out.reserved = 0;
+        out.in_consumed = in_off;
+        out.out_produced = o.pos;
+        res[ci] = out;
+    }
+}
+
+} // namespace xfg
+
+extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,
+                                         void *d_raw, void *d_res, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (n + xfg::WAVES_PER_BLOCK - 1) / xfg::WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(xfg::inflate_chunks_kernel, dim3(blocks), dim3(64 * xfg::WAVES_PER_BLOCK), 0, stream,
+                       (const uint8_t *)d_comp, (const xfg_chunk *)d_chunks, n,
+                       (uint8_t *)d_raw, (xfg_result *)d_res);
+    return hipGetLastError();
+}

@@ -1,0 +1,214 @@
+/*
+ * xflate_amd.h -- C ABI of libxflate_amd.so: MI355X-native XFLATE/DEFLATE decode.
+ *
+ * This is the drop-in boundary for the read path of dsnet/compress
+ * (xflate.NewReader / Reader.Read / Seek / Close, flate.NewReader).  The
+ * reference has no FFI on this path (it is pure Go); the shape follows the
+ * only native precedent in the reference, the create / stream / destroy cgo
+ * shim with caller-owned buffers in internal/cgo/flate/flate.go:18-44,98-133.
+ * Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no C++ or torch types.
+ *  - int return of the xfg_* transport calls: 0 = XFG_OK, otherwise an XFG_E_*
+ *    code (HIP failure, bad argument).  DEFLATE/XFLATE *format* errors are
+ *    never transport errors: they are reported per chunk in xfg_result.status
+ *    and, in the Reader API, as the reference's error classes (XFG_ERR_*).
+ *  - No pointer passed in is retained after the call returns (cgo pointer
+ *    rules), except the callbacks / user pointer handed to xfg_reader_new,
+ *    which live until xfg_reader_free.
+ *  - One xfg_ctx per (thread, device).  Calls on different contexts are
+ *    thread-safe; calls on the same context must be serialised by the caller
+ *    (the reference Reader is single-goroutine, xflate/reader.go:75-95).
+ */
+#ifndef XFLATE_AMD_H
+#define XFLATE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- transport status -------------------------------------------------- */
+#define XFG_OK            0
+#define XFG_E_ARG         1   /* bad argument (null pointer, range, alignment, limit) */
+#define XFG_E_HIP         2   /* HIP runtime call failed; see xfg_last_error()        */
+#define XFG_E_NODEVICE    3   /* no usable MI355X-class device                        */
+#define XFG_E_NOMEM       4
+#define XFG_E_LIMIT       5   /* a chunk exceeds XFG_MAX_CHUNK_COMP / XFG_MAX_CHUNK_RAW */
+
+/* ---- per-chunk decode status (xfg_result.status) -----------------------
+ * 0..2 are the reference's three outcomes of inflating one chunk
+ * (flate/reader.go:58-88): io.EOF after a final block, errors.Corrupted,
+ * io.ErrUnexpectedEOF.  3..4 are xflate.Reader's own post-chunk checks
+ * (xflate/reader.go:190-202).  6 only occurs without XFG_CHUNK_VERIFY. */
+#define XFG_ST_OK             0
+#define XFG_ST_CORRUPTED      1
+#define XFG_ST_UNEXPECTED_EOF 2
+#define XFG_ST_SIZE_MISMATCH  3   /* consumed != csize(+5) or produced != rsize (reader.go:199)  */
+#define XFG_ST_NO_SYNC        4   /* chunk does not end in 00 00 ff ff        (reader.go:190)  */
+#define XFG_ST_INTERNAL       5
+#define XFG_ST_OUT_FULL       6   /* raw_size capacity reached on a chunk without VERIFY        */
+
+/* ---- chunk descriptor -------------------------------------------------
+ * One independently decodable unit: an XFLATE chunk as located by the index
+ * (xflate/index.go:27-31; csize/rsize of xflate/reader.go:265-269), or a whole
+ * plain DEFLATE stream for flate.NewReader. */
+#define XFG_CHUNK_END_BLOCK  0x01u  /* decode chunk || 01 00 00 ff ff  (chunkReader, xflate/reader.go:32-70) */
+#define XFG_CHUNK_SYNC       0x02u  /* deflateType: require trailing 00 00 ff ff (reader.go:190)             */
+#define XFG_CHUNK_VERIFY     0x04u  /* require consumed == comp_size(+5) and produced == raw_size (reader.go:199) */
+#define XFG_CHUNK_FOOTER     0x08u  /* footerType: the stream ends inside the chunk, no +5 (reader.go:196-198)    */
+#define XFG_CHUNK_RFC_REP16  0x10u  /* code-length symbol 16 repeats the previous array entry (RFC 1951 / Go
+                                       stdlib, the inflater xflate.Reader calls: xflate/flate.go:43); unset =
+                                       the in-repo flate package's rule (flate/prefix.go:127-142)            */
+/* what xflate.Reader implies for each record type */
+#define XFG_CHUNK_XFLATE_DEFLATE (XFG_CHUNK_END_BLOCK | XFG_CHUNK_SYNC | XFG_CHUNK_VERIFY | XFG_CHUNK_RFC_REP16)
+#define XFG_CHUNK_XFLATE_INDEX   (XFG_CHUNK_END_BLOCK | XFG_CHUNK_VERIFY | XFG_CHUNK_RFC_REP16)
+#define XFG_CHUNK_XFLATE_FOOTER  (XFG_CHUNK_END_BLOCK | XFG_CHUNK_VERIFY | XFG_CHUNK_FOOTER | XFG_CHUNK_RFC_REP16)
+
+#define XFG_MAX_CHUNK_COMP ((1u << 28) - 64)   /* bytes of compressed data per chunk   */
+#define XFG_MAX_CHUNK_RAW  ((1u << 31) - 64)   /* bytes of decompressed data per chunk */
+
+typedef struct {
+    uint64_t comp_off;    /* byte offset of the chunk in the compressed buffer        */
+    uint64_t comp_size;   /* csize                                                    */
+    uint64_t raw_off;     /* byte offset of the chunk's output in the raw buffer      */
+    uint64_t raw_size;    /* rsize; also the output capacity of this chunk            */
+    uint32_t flags;       /* XFG_CHUNK_*                                              */
+    uint32_t reserved;    /* must be 0                                                */
+} xfg_chunk;
+
+typedef struct {
+    int32_t  status;        /* XFG_ST_*                                                            */
+    uint32_t reserved;
+    int64_t  in_consumed;   /* flateReader.InputOffset at the end of the chunk (xflate/flate.go:31) */
+    int64_t  out_produced;  /* flateReader.OutputOffset; bytes [raw_off, raw_off+out_produced) are valid */
+} xfg_result;
+
+typedef struct xfg_ctx xfg_ctx;
+
+/* ---- device context ---------------------------------------------------- */
+int  xfg_device_count(void);
+/* One context = one HIP device + one stream + reusable staging buffers. */
+int  xfg_create(int device, xfg_ctx **out);
+void xfg_destroy(xfg_ctx *ctx);
+const char *xfg_strerror(int code);
+/* Text of the last HIP failure on this thread ("" if none). */
+const char *xfg_last_error(void);
+
+/*
+ * Decode n chunks, host pointers, blocking.  Replaces the per-chunk loop of
+ * xflate.Reader.Read (xflate/reader.go:183-212: flateReader.Read over
+ * chunkReader, then the sync/size checks) for a whole batch: copies comp to
+ * the device, launches the inflate kernels, copies raw and res back.
+ *   comp/comp_len   compressed bytes that every chunk's [comp_off, comp_off+comp_size) lies in
+ *   raw/raw_len     output; every chunk's [raw_off, raw_off+raw_size) must lie in it and not overlap another's
+ *   res[n]          per-chunk outcome
+ */
+int xfg_decode(xfg_ctx *ctx, const uint8_t *comp, size_t comp_len,
+               const xfg_chunk *chunks, size_t n,
+               uint8_t *raw, size_t raw_len, xfg_result *res);
+
+/*
+ * Same, device-resident and asynchronous: all four pointers are device
+ * pointers (d_comp at least 16-byte aligned), the work is enqueued on
+ * `hip_stream` (a hipStream_t; NULL = the context's stream) and the call
+ * returns without synchronising.  Allocates nothing per call once the context has
+ * seen a batch of this size.  This is what bench.py times.
+ */
+int xfg_decode_device(xfg_ctx *ctx, const void *d_comp, size_t comp_len,
+                      const void *d_chunks, size_t n,
+                      void *d_raw, size_t raw_len, void *d_res, void *hip_stream);
+/* Wait for everything enqueued on the context's stream. */
+int xfg_sync(xfg_ctx *ctx);
+
+/* ======================================================================== */
+/* Host-side mirror of the reference reader                                  */
+/* ======================================================================== */
+
+/* Error classes of the reference (internal/errors/errors.go:36-56), plus the
+ * three io sentinels its tests compare by identity. */
+#define XFG_ERR_NONE            0
+#define XFG_ERR_INTERNAL        1    /* errors.Internal  */
+#define XFG_ERR_INVALID         2    /* errors.Invalid   */
+#define XFG_ERR_DEPRECATED      3    /* errors.Deprecated*/
+#define XFG_ERR_CORRUPTED       4    /* errors.Corrupted */
+#define XFG_ERR_CLOSED          5    /* errors.Closed    */
+#define XFG_ERR_EOF             16   /* io.EOF           */
+#define XFG_ERR_UNEXPECTED_EOF  17   /* io.ErrUnexpectedEOF */
+#define XFG_ERR_IO              18   /* the caller's read/seek callback failed */
+#define XFG_ERR_DEVICE          19   /* transport failure (see xfg_last_error) */
+
+/* io.ReadSeeker supplied by the caller (xflate.NewReader's rs argument).
+ * read: up to n bytes into buf, returns bytes read, 0 at EOF, <0 on error.
+ * seek: whence 0/1/2 = io.SeekStart/Current/End, returns new offset or <0. */
+typedef int64_t (*xfg_read_fn)(void *user, uint8_t *buf, int64_t n);
+typedef int64_t (*xfg_seek_fn)(void *user, int64_t offset, int whence);
+
+typedef struct xfg_reader xfg_reader;
+
+/* record types of xflate/index.go:7-12 */
+#define XFG_REC_UNKNOWN 0
+#define XFG_REC_DEFLATE 1
+#define XFG_REC_INDEX   2
+#define XFG_REC_FOOTER  3
+typedef struct {
+    int64_t comp_offset;   /* ENDING offsets, as in xflate/index.go:27-31 */
+    int64_t raw_offset;
+    int32_t type;
+    int32_t reserved;
+} xfg_record;
+
+/*
+ * xflate.NewReader(rs, nil)  (xflate/reader.go:113-117).  Seeks rs to its end,
+ * decodes footer and indexes on the host (decodeFooter :430, decodeIndexes
+ * :296), leaves the reader at raw offset 0.  Like the reference it returns a
+ * non-NULL reader together with a non-zero error class when the index is bad;
+ * that reader's Read/Seek/Close then report the sticky error.
+ * Returns an XFG_ERR_* class.
+ */
+int xfg_reader_new(xfg_ctx *ctx, xfg_read_fn rd, xfg_seek_fn sk, void *user, xfg_reader **out);
+/* xflate.(*Reader).Reset (reader.go:124). */
+int xfg_reader_reset(xfg_reader *r, xfg_read_fn rd, xfg_seek_fn sk, void *user);
+/* xflate.(*Reader).Read (reader.go:162): returns the byte count (> 0) or 0 with *err set. */
+int64_t xfg_reader_read(xfg_reader *r, uint8_t *buf, int64_t n, int *err);
+/* xflate.(*Reader).Seek (reader.go:221): returns the new offset, or 0 with *err set. */
+int64_t xfg_reader_seek(xfg_reader *r, int64_t offset, int whence, int *err);
+/* xflate.(*Reader).Close (reader.go:282): idempotent; returns the sticky error class. */
+int xfg_reader_close(xfg_reader *r);
+void xfg_reader_free(xfg_reader *r);
+/* The merged index (what reader.go:76 says it wants to export): n records, ending offsets. */
+int64_t xfg_reader_num_records(const xfg_reader *r);
+int xfg_reader_get_records(const xfg_reader *r, xfg_record *out, int64_t cap);
+/* Bytes pulled through the read callback so far (countReadSeeker, xflate/reader_test.go:19-28). */
+int64_t xfg_reader_bytes_read(const xfg_reader *r);
+/* How many chunks one device launch may cover (read-ahead window), default 256 MiB raw. */
+int xfg_reader_set_window(xfg_reader *r, int64_t max_raw_bytes);
+
+/*
+ * Parse footer + indexes of a whole in-memory XFLATE stream and emit the
+ * device chunk table for every record (deflate, index and footer records, in
+ * stream order), ready for xfg_decode / xfg_decode_device.  Host only.
+ * Returns an XFG_ERR_* class; *n_out = number of descriptors written (<= cap),
+ * or the number required when chunks == NULL.
+ */
+int xfg_index_parse(const uint8_t *stream, size_t len, xfg_chunk *chunks, size_t cap, size_t *n_out);
+
+/*
+ * flate.NewReader(r, nil) + ReadAll + Close in one call (flate/reader.go:39-97)
+ * for an in-memory stream: inflates one plain DEFLATE stream on the device
+ * with the in-repo flate package's semantics.  *err = XFG_ERR_NONE (clean
+ * io.EOF), XFG_ERR_CORRUPTED or XFG_ERR_UNEXPECTED_EOF; *in_off / *out_off are
+ * Reader.InputOffset / OutputOffset (flate/reader.go:15-16).  out_cap too
+ * small returns XFG_E_NOMEM with *out_off = bytes that fit.
+ */
+int xfg_flate_decode(xfg_ctx *ctx, const uint8_t *in, size_t in_len,
+                     uint8_t *out, size_t out_cap,
+                     int64_t *in_off, int64_t *out_off, int *err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFLATE_AMD_H */
