@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- XFLATE decode throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (xfg_decode_device: the inflate kernels) over this
+rank's shard of a synthetic XFLATE stream that is already resident in HBM.  The
+workload is BASELINE.json configs[1]: 1 GiB of raw data per GPU in 64 KiB chunks,
+round-robin huffman / repeats / digits generators, zlib level 6, one sync flush per
+chunk, 4096 records per index.  With N ranks the stream is N GiB and rank k owns the
+index records [k*16384, (k+1)*16384) (index-range sharding; no data-path collective),
+so per-GPU work is fixed: "scaling": "weak".
+
+Rank 0 prints ONE JSON line with the metric plus
+  roofline     achieved = (sum csize + sum rsize) per launch / mean kernel time (HIP events
+               on the launch stream) against the 8 TB/s HBM peak
+  cpu_baseline the CPU oracle (oracle/inflate_oracle.c, a port of the reference's flate
+               reader) decoding the same chunks on this box's host cores, threads stated.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (chunks per GPU, chunk size, kinds, zlib level, distinct chunks generated)
+    "c2": (16384, 65536, ("huffman", "repeats", "digits"), 6, 768),
+    "c3": (16384, 262144, ("huffman", "repeats", "digits"), 6, 384),     # 4 GiB per GPU, 256 KiB chunks
+    "small": (768, 65536, ("huffman", "repeats", "digits"), 6, 96),
+}
+
+
+def build_shard(name, rank):
+    """-> dict(stream bytes of this rank's chunks (deflate records only), descriptors, distinct raws)."""
+    import zlib
+    from compress_amd import capi, synth
+    n_chunks, chunk_size, kinds, level, nd = WORKLOADS[name]
+    first = rank * n_chunks                       # global index of this rank's first record
+
+    def make(j):
+        kind = kinds[j % len(kinds)]
+        raw = synth.GENERATORS[kind](chunk_size, 1 + 1000003 * (j % len(kinds)) + j)
+        return raw, synth.deflate_chunk(raw, level, zlib.Z_DEFAULT_STRATEGY)
+
+    with ThreadPoolExecutor(16) as ex:
+        made = list(ex.map(make, range(nd)))
+    comp = bytearray()
+    descs = (capi.Chunk * n_chunks)()
+    for i in range(n_chunks):
+        raw, c = made[(first + i) % nd]
+        descs[i] = capi.Chunk(len(comp), len(c), i * chunk_size, len(raw), capi.CHUNK_XFLATE_DEFLATE, 0)
+        comp += c
+    return {"comp": bytes(comp), "descs": descs, "n": n_chunks, "chunk_size": chunk_size, "made": made,
+            "first": first, "nd": nd, "raw_len": n_chunks * chunk_size}
+
+
+def cpu_baseline(shard, threads):
+    """The oracle (a C port of the reference's inflater) over the same descriptors on host threads."""
+    import oracle
+    lib = oracle.lib()
+    n = shard["n"]
+    comp = shard["comp"]
+    raw = ctypes.create_string_buffer(shard["raw_len"])
+    res = (oracle.OrcResult * n)()
+    descs = ctypes.cast(shard["descs"], ctypes.c_void_p)
+    max_c = max(shard["descs"][i].comp_size for i in range(n))
+    per = (n + threads - 1) // threads
+
+    def work(t):
+        tmp = ctypes.create_string_buffer(max_c + 16)
+        lo = t * per
+        cnt = max(0, min(per, n - lo))
+        if cnt:
+            lib.oracle_inflate_batch(comp, descs, lo, cnt, raw, res, tmp)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    bad = sum(1 for i in range(n) if res[i].status != 0 or res[i].out_produced != shard["descs"][i].raw_size)
+    return dt, bad, raw
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from compress_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    shard = build_shard(args.workload, rank)
+    n = shard["n"]
+    comp_len, raw_len = len(shard["comp"]), shard["raw_len"]
+
+    ctx = capi.Context(local_rank)
+    d_comp = torch.frombuffer(bytearray(shard["comp"]) + bytearray(64), dtype=torch.uint8).to(dev)
+    d_chunks = torch.frombuffer(bytearray(bytes(shard["descs"])), dtype=torch.uint8).to(dev)
+    d_raw = torch.zeros(raw_len + 64, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
+    # A non-default torch stream: its handle is what the kernels are launched on, so the
+    # torch.cuda.Event pairs below time exactly that stream.
+    stream = torch.cuda.Stream(dev)
+    assert stream.cuda_stream != 0
+
+    def step():
+        ctx.decode_device(d_comp.data_ptr(), comp_len, d_chunks.data_ptr(), n,
+                          d_raw.data_ptr(), raw_len, d_res.data_ptr(), stream.cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    torch.cuda.synchronize(dev)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize(dev)
+
+    # parity gate (untimed): every chunk ok, sizes as promised, bytes equal to the generator's raw data
+    verified = None
+    if not args.no_verify:
+        res = d_res.cpu().numpy().view("i4,u4,i8,i8")
+        ok = bool((res["f0"] == 0).all()) and bool((res["f3"] == shard["chunk_size"]).all())
+        nd, cs = shard["nd"], shard["chunk_size"]
+        distinct = torch.frombuffer(bytearray(b"".join(m[0] for m in shard["made"])), dtype=torch.uint8).to(dev).view(nd, cs)
+        idx = (torch.arange(n, device=dev) + shard["first"]) % nd
+        got = d_raw[:raw_len].view(n, cs)
+        eq = True
+        for lo in range(0, n, 2048):                          # bounded temporaries
+            eq = eq and bool(torch.equal(got[lo:lo + 2048], distinct[idx[lo:lo + 2048]]))
+        verified = ok and eq
+        del distinct
+        if not verified:
+            print(json.dumps({"error": "parity check failed on rank %d" % rank, "status_ok": ok, "bytes_equal": eq}))
+            sys.exit(1)
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in evs) / max(args.steps, 1)
+
+    if dist is not None:
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+
+    out = None
+    if rank == 0:
+        total_raw = raw_len * world * args.steps
+        value = total_raw / elapsed / 1e9
+        algo_bytes = comp_len + raw_len                      # per launch, this rank (every rank has the same shape)
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        n_chunks, chunk_size, kinds, level, nd = WORKLOADS[args.workload]
+        out = {
+            "metric": "decompressed GB/s (node), xflate decode",
+            "value": round(value, 3),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic (%d distinct chunks per kind-mix tiled to %d chunks per GPU; seeds in compress_amd/synth.py)" % (nd, n_chunks),
+            "config": {"workload": "%s: %d x %d KiB chunks per GPU (%s), zlib level %d, sync flush per chunk; "
+                                   "index-range sharded over %d GPU(s)" % (args.workload, n_chunks, chunk_size >> 10,
+                                                                          "/".join(kinds), level, world),
+                       "raw_bytes_per_gpu": raw_len, "comp_bytes_per_gpu": comp_len,
+                       "ratio": round(raw_len / comp_len, 3), "verified_bit_exact": verified},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "inflate_chunks_kernel", "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if not args.no_cpu:
+            import oracle
+            oracle.build()
+            threads = min(16, os.cpu_count() or 1)
+            dt, bad, _ = cpu_baseline(shard, threads)
+            out["cpu_baseline"] = {"value": round(raw_len / dt / 1e9, 3), "unit": "GB/s", "cores": threads,
+                                   "kind": "port",
+                                   "sample": "this rank's whole shard once (%d chunks, %.2f GiB raw), oracle/inflate_oracle.c "
+                                             "over %d host threads; %d bad chunks" % (n, raw_len / 2**30, threads, bad)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
