@@ -1,7 +1,22 @@
 // inflate_kernel.hip -- DEFLATE inflate of independent XFLATE chunks on gfx950.
 //
-// One wavefront owns one chunk.  A workgroup
-// is 4 independent waves; they share nothing and never barrier.
+// One wavefront owns one chunk at a time.  A
+// workgroup is 4 independent waves; they share nothing and never barrier.  The
+// grid is persistent (3 workgroups per CU) and walks the chunk table round-robin.
+//
+// Inside a Huffman block the 64 lanes decode 64 consecutive 512-bit segments of
+// the bit stream at once (decode_huffman_block):
+//   stage 1  speculative decode: lane i starts at segment boundary i, which is
+//            almost never a code-word boundary; prefix codes self-synchronise, so
+//            its END position is usually right anyway.  Lanes then restart from
+//            their predecessor's end until the chain of starts is stable; the
+//            stable prefix of lanes is exactly the serial decoder's token stream.
+//            A last pass writes literals to their final positions (offsets from a
+//            wave prefix sum of bytes per lane) and emits match tokens.
+//   stage 2  match resolution: every lane copies its own matches; a match is
+//            ready when all of its source bytes are final, which is tracked with
+//            a wave-wide watermark.  Overlapping matches double their period per
+//            round, so no copy ever reads bytes written in the same round.
 //
 // What this restates, in the reference's terms (all under /root/reference):
 //   chunkReader            xflate/reader.go:32-70      -> win_load(): chunk || 01 00 00 ff ff is a virtual stream
@@ -10,8 +25,8 @@
 //   ReadPrefixCodes        flate/prefix.go:83-194      -> read_dynamic_header()
 //   GeneratePrefixes       internal/prefix/prefix.go:326-384 -> build_table() steps 1-3 (histogram, Kraft, canonical rank)
 //   Decoder.Init           internal/prefix/decoder.go:51-136 -> build_table() steps 4-5 (root table + sub-tables in LDS)
-//   readBlock              flate/reader.go:162-250     -> decode_block()
-//   dictDecoder            flate/dict_decoder.go:86-132 -> match_copy(): the output buffer is the window
+//   readBlock              flate/reader.go:162-250     -> decode_huffman_block() / decode_segment()
+//   dictDecoder            flate/dict_decoder.go:86-132 -> resolve_matches(): the output buffer is the window
 //   Read's post-chunk checks xflate/reader.go:186-202  -> epilogue of inflate_chunk()
 //
 // The decode state (bit buffer, positions, table entries) is wave-uniform and
@@ -20,6 +35,7 @@
 // construction, stored-block and match copies.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/xflate_amd.h"
 
 namespace xfg {
@@ -38,8 +54,14 @@ constexpr int CLEN_ROOT = 7;            // code-length code: max length 7, never
 constexpr int LIT_TAB = 1344;           // >= enough(286, 10, 15) = 1334 entries
 constexpr int DIST_TAB = 416;           // >= enough(30, 8, 15)  = 402 entries
 constexpr int CLEN_TAB = 128;
-constexpr int WIN_BYTES = 1024;         // compressed-stream window: two 512-byte halves
+constexpr int WIN_BYTES = 1024;         // header reader's window: two 512-byte halves
 constexpr int MAX_HIST = 32768;         // flate/common.go:16
+constexpr int SEG_BITS = 512;           // bits of compressed stream per lane and batch
+constexpr int BATCH_BYTES = 64 * SEG_BITS / 8;
+constexpr int BWIN_BYTES = BATCH_BYTES + 64;    // batch window: 16-byte alignment slack + 8-byte over-read
+constexpr int T_MAX = 64;               // match tokens per lane and batch (a lane stops its segment there)
+constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix
+constexpr int SCRATCH_WORDS_PER_WAVE = T_MAX * 64;
 
 // Table entry (u32):
 //   [4:0]   bits to consume for this code word (total code length, sub-table entries included)
@@ -84,7 +106,7 @@ struct WaveLds {
     u32 lit[LIT_TAB];
     u32 dist[DIST_TAB];
     u32 clen[CLEN_TAB];
-    u64 win[WIN_BYTES / 8];
+    u64 win[BWIN_BYTES / 8];  // batch window; its first WIN_BYTES double as the header reader's ring
     u16 sorted[320];        // symbols in canonical (length, symbol) order
     u8  lens[320];          // code lengths: [0,hlit) literal/length, [hlit, hlit+hdist) distance
     u8  clens[32];          // code lengths of the code-length code
@@ -199,6 +221,17 @@ __device__ __forceinline__ i64 in_offset(const Reader &r) {
     return (consumed + 7) >> 3;
 }
 
+// Reposition the header reader at an absolute bit position of the stream.
+__device__ __forceinline__ void reader_seek(Reader &r, u32 bitpos) {
+    r.bytepos = bitpos >> 3;
+    r.bitbuf = 0;
+    r.bitcnt = 0;
+    r.blk_hi = -4;                                              // nothing resident
+    refill(r);
+    consume(r, bitpos & 7);
+}
+__device__ __forceinline__ u32 reader_bitpos(const Reader &r) { return r.bytepos * 8 - r.bitcnt; }
+
 // ---------------------------------------------------------------------------
 // Canonical prefix-code table construction, wave-cooperative, directly in LDS.
 // Returns 0 = ok, 1 = empty code (decode with it is an error), 2 = invalid
@@ -282,7 +315,7 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
     const u32 end_root = uni(L.endr[lim]);
     for (u32 u = lane; u < end_root; u += 64) {
         u32 l = 1;
-        while (u >= L.endr[l]) l++;
+        while (l < (u32)ROOT && u >= L.endr[l]) l++;
         const u32 sym = L.sorted[L.offs[l] + (u >> (ROOT - l)) - L.first[l]];
         tab[__brev(u) >> (32 - ROOT)] = sym_entry(TYPE, sym, l);
     }
@@ -472,57 +505,294 @@ __device__ void build_fixed(WaveLds &L, u32 lane) {
     build_table<T_DIST, DIST_ROOT>(L, L.dist, L.clens, 32, lane);
 }
 
-// readBlock (flate/reader.go:162-250).  Returns XFG_ST_OK at the end-of-block symbol.
-__device__ int decode_block(Reader &r, Out &o, WaveLds &L, u32 lane, int lit_state, int dist_state) {
-    for (;;) {
-        if (lit_state == 1) return XFG_ST_CORRUPTED;            // empty literal tree: prefix/reader.go:199-201
-        refill(r);
-        u32 e = lookup<LIT_ROOT>(L.lit, r.bitbuf);
-        if ((i32)e_nbits(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
-        consume(r, e_nbits(e));
-        const u32 kind = e_kind(e);
-        if (kind == K_LIT) {
-            if (o.pos >= o.cap) return XFG_ST_OUT_FULL;
-            if (lane == 0) o.raw[o.pos] = (u8)e_val(e);
-            o.pos++;
-            continue;
+// ---------------------------------------------------------------------------
+// Lane-parallel decode of one Huffman block: readBlock (flate/reader.go:162-250)
+// and dictDecoder (flate/dict_decoder.go:86-132) for 64 segments at a time.
+// ---------------------------------------------------------------------------
+enum : u32 { F_NONE = 0, F_EOB = 1, F_CORRUPT = 2, F_EOF = 3, F_DIST = 4, F_PANIC = 5 };
+
+struct Seg {
+    u32 end;        // bit position after the last token decoded
+    u32 nout;       // bytes those tokens produce
+    u32 nmatch;     // match tokens among them
+    u32 flag;       // F_*: why the lane stopped before its segment end
+};
+
+__device__ __forceinline__ u64 lds_load64(const u8 *p) {
+    u64 v;
+    __builtin_memcpy(&v, p, 8);                                 // ds_read_b64, any byte alignment
+    return v;
+}
+
+// Load the compressed bytes [wb0, wb0 + BWIN_BYTES) of the virtual stream into L.win.
+// wb0 (may be negative by < 16) is chosen so that the global address is 16-byte aligned.
+__device__ void load_batch_window(const Reader &r, WaveLds &L, i32 wb0, u32 lane) {
+    const u8 *src = r.comp + r.base_al + r.lead;                // stream byte 0
+    u8 *dst = reinterpret_cast<u8 *>(L.win);
+    for (u32 o = lane * 16; o < (u32)BWIN_BYTES; o += 64 * 16) {
+        const i32 ci = wb0 + (i32)o;
+        uint4 v;
+        if (ci >= 0 && ci + 16 <= (i32)r.csize) {
+            v = *reinterpret_cast<const uint4 *>(src + ci);
+        } else {
+            u32 w[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 16; j++) {
+                const i32 idx = ci + j;
+                u32 bb = 0;
+                if (idx >= 0) {
+                    if (idx < (i32)r.csize) bb = src[idx];
+                    else if (idx < (i32)r.total) {
+                        const u32 t = (u32)idx - r.csize;       // 01 00 00 ff ff
+                        bb = (t == 0) ? 0x01u : (t >= 3 ? 0xffu : 0x00u);
+                    }
+                }
+                w[j >> 2] |= bb << (8 * (j & 3));
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        if (kind == K_EOB) return XFG_ST_OK;
-        if (kind != K_BASE) return XFG_ST_CORRUPTED;            // symbols 286/287 or the degenerate filler
-        u32 xb = e_extra(e);
-        if ((i32)xb > avail(r)) return XFG_ST_UNEXPECTED_EOF;
-        const u32 len = e_val(e) + peek(r, xb);
-        consume(r, xb);
-        // distance symbol
-        if (dist_state == 1) return XFG_ST_CORRUPTED;
-        e = lookup<DIST_ROOT>(L.dist, r.bitbuf);
-        if ((i32)e_nbits(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
-        consume(r, e_nbits(e));
-        if (e_kind(e) != K_BASE) return XFG_ST_CORRUPTED;
-        xb = e_extra(e);
-        if ((i32)xb > avail(r)) return XFG_ST_UNEXPECTED_EOF;
-        const u32 dist = e_val(e) + peek(r, xb);
-        consume(r, xb);
-        const u32 hist = o.pos < (u32)MAX_HIST ? o.pos : (u32)MAX_HIST;     // dictDecoder.HistSize
-        if (dist > hist) return XFG_ST_CORRUPTED;               // flate/reader.go:223-225
-        if (len > o.cap - o.pos) {
-            match_copy(o, o.cap - o.pos, dist, lane);           // keep what fits, then report
-            return XFG_ST_OUT_FULL;
-        }
-        match_copy(o, len, dist, lane);
+        *reinterpret_cast<uint4 *>(dst + o) = v;
     }
 }
 
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
-inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
-                      u8 *__restrict__ raw, xfg_result *__restrict__ res)
+// Decode the tokens that START in [start, seg_end) (or until T_MAX matches).
+// EMIT = false: count only.  EMIT = true: literals go to raw[] at obase.., matches to mlist.
+template <bool EMIT>
+__device__ __forceinline__ Seg decode_segment(const WaveLds &L, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
+                                              bool dist_empty, u8 *raw, u32 obase, u32 cap, u32 *mlist, u32 lane,
+                                              u32 &err_out)
 {
-    __shared__ WaveLds lds[WAVES_PER_BLOCK];
-    const u32 wave = uni(threadIdx.x >> 6);
-    const u32 lane = threadIdx.x & 63;
-    const u32 ci = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (ci >= n) return;
-    WaveLds &L = lds[wave];
+    const u8 *win = reinterpret_cast<const u8 *>(L.win);
+    u32 pos = start, nout = 0, nm = 0, flag = F_NONE, gap = 0;
+    u32 guard = 0;
+    while (pos < seg_end) {
+        if (++guard > (u32)SEG_BITS + 64) { flag = F_PANIC; break; }   // every token consumes >= 1 bit
+        const u64 bits = lds_load64(win + ((i32)(pos >> 3) - wb0)) >> (pos & 7);    // >= 57 valid bits
+        u32 e = L.lit[(u32)bits & ((1u << LIT_ROOT) - 1)];
+        if (e_kind(e) == K_SUB)
+            e = L.lit[e_val(e) + (((u32)(bits >> LIT_ROOT)) & ((1u << e_extra(e)) - 1))];
+        u32 n = e_nbits(e);
+        if (pos + n > total_bits) { flag = F_EOF; break; }
+        const u32 kind = e_kind(e);
+        if (kind == K_LIT) {
+            if (EMIT) { if (obase + nout < cap) raw[obase + nout] = (u8)e_val(e); }
+            nout++; gap++;
+            pos += n;
+            continue;
+        }
+        pos += n;
+        if (kind == K_EOB) { flag = F_EOB; break; }
+        if (kind != K_BASE) { flag = F_CORRUPT; break; }        // 286/287 or the degenerate filler
+        const u32 xb = e_extra(e);
+        if (pos + xb > total_bits) { flag = F_EOF; break; }
+        const u32 len = e_val(e) + (((u32)(bits >> n)) & ((1u << xb) - 1));
+        pos += xb; n += xb;
+        if (dist_empty) { flag = F_CORRUPT; break; }            // decode with empty prefix tree
+        const u32 db = (u32)(bits >> n);
+        u32 d = L.dist[db & ((1u << DIST_ROOT) - 1)];
+        if (e_kind(d) == K_SUB)
+            d = L.dist[e_val(d) + ((db >> DIST_ROOT) & ((1u << e_extra(d)) - 1))];
+        const u32 dn = e_nbits(d);
+        if (pos + dn > total_bits) { flag = F_EOF; break; }
+        pos += dn; n += dn;
+        if (e_kind(d) != K_BASE) { flag = F_CORRUPT; break; }   // distance symbols 30/31 or the filler
+        const u32 dxb = e_extra(d);
+        if (pos + dxb > total_bits) { flag = F_EOF; break; }
+        const u32 dist = e_val(d) + (((u32)(bits >> n)) & ((1u << dxb) - 1));
+        pos += dxb;
+        if (EMIT) {
+            const u32 dst = obase + nout;
+            const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;       // dictDecoder.HistSize
+            if (dist > hist) { flag = F_DIST; err_out = nout; break; }         // flate/reader.go:223-225
+            mlist[nm * 64 + lane] = (len - 3) | ((dist - 1) << 8) | (gap << 23);
+        }
+        nout += len; nm++; gap = 0;
+        if (nm == (u32)T_MAX) break;                            // behaves like a segment end
+    }
+    Seg r;
+    r.end = pos; r.nout = nout; r.nmatch = nm; r.flag = flag;
+    return r;
+}
+
+__device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 lane, u32 &total) {
+    u32 incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(incl, d);
+        if (lane >= (u32)d) incl += t;
+    }
+    total = uni(__shfl(incl, 63));
+    return incl - v;
+}
+
+__device__ __forceinline__ void mem_sync() {
+    // Make this wave's global stores visible to its own later loads: both go through the
+    // CU's write-through L1, so waiting for the stores (workgroup-scope release) suffices.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Copy n bytes from raw[s..] to raw[d..], ranges disjoint, any alignment.
+__device__ __forceinline__ void copy_disjoint(u8 *raw, u32 d, u32 s, u32 n) {
+    u32 j = 0;
+    for (; j + 16 <= n; j += 16) {
+        u64 a, b2;
+        __builtin_memcpy(&a, raw + s + j, 8);
+        __builtin_memcpy(&b2, raw + s + j + 8, 8);
+        __builtin_memcpy(raw + d + j, &a, 8);
+        __builtin_memcpy(raw + d + j + 8, &b2, 8);
+    }
+    if (j + 8 <= n) {
+        u64 a;
+        __builtin_memcpy(&a, raw + s + j, 8);
+        __builtin_memcpy(raw + d + j, &a, 8);
+        j += 8;
+    }
+    for (; j < n; j++) raw[d + j] = raw[s + j];
+}
+
+// Stage 2: resolve the match tokens of one batch.  Lane i owns the tokens of segment i in
+// order; my_base is where its output starts.  All literals of the batch are already in place.
+__device__ void resolve_matches(u8 *raw, u32 cap, const u32 *mlist, u32 nm, u32 my_base, u32 lane) {
+    u32 k = 0, cur = my_base;
+    u32 dst = 0, src = 0, rem = 0;
+    bool loaded = false;
+    for (u32 round = 0; round < 64u * T_MAX * 10u; round++) {   // each round retires >= 1 copy step
+        const bool have = k < nm;
+        if (have && !loaded) {
+            const u32 m = mlist[k * 64 + lane];
+            const u32 len = (m & 255) + 3, dist = ((m >> 8) & 32767) + 1, gap = m >> 23;
+            dst = cur + gap;
+            src = dst - dist;
+            rem = len;
+            loaded = true;
+        }
+        const u64 pending = __ballot(have);
+        if (pending == 0) break;
+        // Everything below the destination of the earliest unresolved match is final.
+        const u32 first = (u32)__ffsll((long long)pending) - 1;
+        const u32 water = uni(__shfl(dst, first));
+        if (have) {
+            // This round copies at most the part of the source that is final now: for an
+            // overlapping match (dist < len) that is dist bytes, and the period doubles per round.
+            u32 n = dst - src;
+            if (n > rem) n = rem;
+            const bool ready = (src + n <= water) || (src >= my_base);
+            if (ready) {
+                u32 cn = n;
+                if (dst >= cap) cn = 0; else if (cn > cap - dst) cn = cap - dst;
+                copy_disjoint(raw, dst, src, cn);
+                dst += n; rem -= n;
+                if (rem == 0) { cur = dst; k++; loaded = false; }
+            }
+        }
+        mem_sync();
+    }
+}
+
+struct BlockEnd {
+    int status;         // XFG_ST_OK = end-of-block symbol reached, anything else ends the chunk
+    u32 bitpos;         // consumed bits of the stream
+};
+
+// Decode one Huffman block that starts at bit position p0.  Output goes to o.raw at o.pos.
+__device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u32 lane, u32 p0,
+                                         int lit_state, int dist_state, u32 *mlist)
+{
+    BlockEnd be;
+    if (lit_state == 1) { be.status = XFG_ST_CORRUPTED; be.bitpos = p0; return be; }   // empty literal tree
+    const u32 total_bits = r.total * 8;
+    const bool dist_empty = dist_state == 1;
+    for (u32 nbatch = 0;; nbatch++) {
+        if (nbatch > total_bits + 4) { be.status = XFG_ST_INTERNAL; be.bitpos = p0; return be; }   // every batch consumes >= 1 bit
+        // ---- compressed window of this batch
+        const i64 abs0 = (i64)(r.base_al + r.lead) + (p0 >> 3);
+        const i32 wb0 = (i32)((abs0 & ~(i64)15) - (i64)(r.base_al + r.lead));
+        wave_sync();
+        load_batch_window(r, L, wb0, lane);
+        wave_sync();
+
+        // ---- stage 1a: speculative passes until the chain of segment starts is stable
+        u32 start = p0 + lane * SEG_BITS;
+        const u32 seg_end = p0 + (lane + 1) * SEG_BITS;
+        bool dirty = true, dead = false;
+        Seg sg;
+        sg.end = start; sg.nout = 0; sg.nmatch = 0; sg.flag = F_NONE;
+        u32 dummy = 0;
+        u32 verified = 64;
+        for (int pass = 1;; pass++) {
+            if (dirty && !dead)
+                sg = decode_segment<false>(L, wb0, start, seg_end, total_bits, dist_empty, nullptr, 0, 0, nullptr, lane, dummy);
+            const u32 pe = __shfl_up(sg.end, 1);
+            const u32 pf = __shfl_up(sg.flag, 1);
+            const u32 pd = __shfl_up((u32)dead, 1);
+            u32 ns = p0;
+            bool nd = false;
+            if (lane > 0) { nd = pd != 0 || pf != F_NONE; ns = pe; }
+            dirty = (nd != dead) || (!nd && ns != start);
+            start = ns; dead = nd;
+            if (dead) { sg.end = 0; sg.nout = 0; sg.nmatch = 0; sg.flag = F_NONE; }
+            const u64 dm = __ballot(dirty);
+            if (dm == 0) { verified = 64; break; }
+            const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
+            if ((pass >= 2 && fd >= 40) || pass >= MAX_PASSES) { verified = fd; break; }
+        }
+        const bool live = !dead && lane < verified;
+        const u64 lm = __ballot(live);
+        const u32 nlive = (u32)__popcll(lm);                      // live lanes are 0 .. nlive-1
+        const u32 lastl = nlive - 1;
+
+        // ---- output offsets
+        u32 total_out;
+        const u32 rel = wave_excl_scan(live ? sg.nout : 0, lane, total_out);
+        const u32 my_base = o.pos + rel;
+
+        // ---- stage 1b: final pass, literals to their places, matches to the token list
+        u32 err_out = 0;
+        Seg fin = sg;
+        if (live)
+            fin = decode_segment<true>(L, wb0, start, seg_end, total_bits, dist_empty, o.raw, my_base, o.cap, mlist, lane, err_out);
+        mem_sync();
+
+        // A distance beyond the history ends the chunk at that token (flate/reader.go:223-225).
+        const u64 em = __ballot(live && fin.flag == F_DIST);
+        u32 nm = live ? fin.nmatch : 0;
+        u32 elane = 64;
+        if (em) {
+            elane = (u32)__ffsll((long long)em) - 1;
+            if (lane > elane) nm = 0;                            // tokens after the error do not exist
+        }
+        // ---- stage 2
+        resolve_matches(o.raw, o.cap, mlist, nm, my_base, lane);
+
+        if (em) {
+            be.status = XFG_ST_CORRUPTED;
+            be.bitpos = uni(__shfl(fin.end, elane));
+            o.pos = uni(__shfl(my_base + err_out, elane));
+            if (o.pos > o.cap) { o.pos = o.cap; be.status = XFG_ST_OUT_FULL; }
+            return be;
+        }
+        const u32 lflag = uni(__shfl(sg.flag, lastl));
+        const u32 lend = uni(__shfl(sg.end, lastl));
+        if (o.pos + total_out > o.cap || total_out > o.cap) {      // more output than the chunk may hold
+            o.pos = o.cap;
+            be.status = XFG_ST_OUT_FULL;
+            be.bitpos = lend;
+            return be;
+        }
+        o.pos += total_out;
+        if (lflag == F_EOB) { be.status = XFG_ST_OK; be.bitpos = lend; return be; }
+        if (lflag == F_CORRUPT) { be.status = XFG_ST_CORRUPTED; be.bitpos = lend; return be; }
+        if (lflag == F_EOF) { be.status = XFG_ST_UNEXPECTED_EOF; be.bitpos = lend; return be; }
+        if (lflag != F_NONE || lend <= p0) { be.status = XFG_ST_INTERNAL; be.bitpos = lend; return be; }
+        p0 = lend;                                                 // next batch
+    }
+}
+
+// Inflate one chunk; returns through *out.  Everything here is wave-uniform control flow.
+__device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 ci,
+                              u8 *__restrict__ raw, xfg_result *__restrict__ res,
+                              WaveLds &L, u32 lane, u32 *mlist)
+{
     xfg_chunk c = chunks[ci];
     c.comp_off = uni64(c.comp_off);
     c.raw_off = uni64(c.raw_off);
@@ -535,7 +805,7 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
     r.csize = uni((u32)c.comp_size);
     r.total = r.csize + ((flags & XFG_CHUNK_END_BLOCK) ? 5u : 0u);
     r.bytepos = 0;
-    r.blk_hi = -1;
+    r.blk_hi = -4;
     r.bitbuf = 0;
     r.bitcnt = 0;
     r.win = L.win;
@@ -551,7 +821,8 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
     int status;
     int tables = 0;                                             // 0 none, 1 fixed, 2 dynamic
 
-    for (;;) {
+    for (u32 nblk = 0;; nblk++) {
+        if (nblk > r.total * 8 + 4) { status = XFG_ST_INTERNAL; break; }   // every block consumes >= 3 bits
         // readBlockHeader (flate/reader.go:100-134)
         refill(r);
         if (avail(r) < 1) { status = XFG_ST_UNEXPECTED_EOF; break; }
@@ -594,7 +865,10 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
                 status = read_dynamic_header(r, L, lane, rfc_rep16, lit_state, dist_state);
                 if (status != XFG_ST_OK) break;
             }
-            status = decode_block(r, o, L, lane, lit_state, dist_state);
+            const BlockEnd be = decode_huffman_block(r, o, L, lane, reader_bitpos(r), lit_state, dist_state, mlist);
+            wave_sync();
+            reader_seek(r, be.bitpos);                          // the window was reused by the block decoder
+            status = be.status;
             if (status != XFG_ST_OK) break;
         }
         // finishBlock (flate/reader.go:253-259)
@@ -633,15 +907,47 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
     }
 }
 
+// Persistent grid: wave w of the grid takes chunks w, w + W, w + 2W, ...
+// scratch holds SCRATCH_WORDS_PER_WAVE u32 (match-token lists) per wave of the grid.
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
+inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
+                      u8 *__restrict__ raw, xfg_result *__restrict__ res,
+                      u32 *__restrict__ scratch)
+{
+    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+    const u32 wave = uni(threadIdx.x >> 6);
+    const u32 lane = threadIdx.x & 63;
+    WaveLds &L = lds[wave];
+    u32 *mlist = scratch + (size_t)(blockIdx.x * WAVES_PER_BLOCK + wave) * SCRATCH_WORDS_PER_WAVE;
+    // Static round-robin over the persistent grid: the trip count is provably wave-uniform.
+    const u32 stride = gridDim.x * WAVES_PER_BLOCK;
+    for (u32 ci = blockIdx.x * WAVES_PER_BLOCK + wave; ci < n; ci += stride)
+        inflate_chunk(comp, chunks, ci, raw, res, L, lane, mlist);
+}
+
 } // namespace xfg
 
+extern "C" uint32_t xfg_grid_blocks(uint32_t n, int num_cu)
+{
+    // 3 workgroups of 4 waves fit one CU (LDS-bound, ~52 KiB each).
+    uint32_t want = (n + xfg::WAVES_PER_BLOCK - 1) / xfg::WAVES_PER_BLOCK;
+    uint32_t cap = (uint32_t)num_cu * 3u;
+    return want < cap ? want : cap;
+}
+
+extern "C" size_t xfg_scratch_bytes(int num_cu)
+{
+    return (size_t)num_cu * 3u * xfg::WAVES_PER_BLOCK * xfg::SCRATCH_WORDS_PER_WAVE * sizeof(uint32_t);
+}
+
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,
-                                         void *d_raw, void *d_res, hipStream_t stream)
+                                         void *d_raw, void *d_res, void *d_scratch,
+                                         int num_cu, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    const uint32_t blocks = (n + xfg::WAVES_PER_BLOCK - 1) / xfg::WAVES_PER_BLOCK;
+    const uint32_t blocks = xfg_grid_blocks(n, num_cu);
     hipLaunchKernelGGL(xfg::inflate_chunks_kernel, dim3(blocks), dim3(64 * xfg::WAVES_PER_BLOCK), 0, stream,
                        (const uint8_t *)d_comp, (const xfg_chunk *)d_chunks, n,
-                       (uint8_t *)d_raw, (xfg_result *)d_res);
+                       (uint8_t *)d_raw, (xfg_result *)d_res, (uint32_t *)d_scratch);
     return hipGetLastError();
 }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -21,7 +22,17 @@ static int hip_fail(hipError_t e, const char *what) {
     g_last_error = buf;
     return XFG_E_HIP;
 }
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, #expr); } while (0)
+// XFG_TRACE=1 in the environment prints every HIP call of this file to stderr.
+static bool trace_on() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("XFG_TRACE"); on = (e && *e && *e != '0') ? 1 : 0; }
+    return on == 1;
+}
+#define HIP_TRY(expr) do { \
+        if (trace_on()) fprintf(stderr, "[xfg] %s\n", #expr); \
+        hipError_t e_ = (expr); \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
 
 extern "C" const char *xfg_last_error(void) { return g_last_error.c_str(); }
 
@@ -45,7 +56,9 @@ extern "C" int xfg_device_count(void) {
 
 struct xfg_ctx {
     int device;
+    int num_cu;
     hipStream_t stream;
+    void *d_scratch;      // match-token lists of the persistent grid (fixed size, allocated once)
     // reusable device staging for the host-pointer path
     void *d_comp; size_t comp_cap;
     void *d_raw; size_t raw_cap;
@@ -77,6 +90,12 @@ extern "C" int xfg_create(int device, xfg_ctx **out) {
     c->device = device;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { xfg_destroy(c); return hip_fail(e, "hipGetDeviceProperties"); }
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = hipMalloc(&c->d_scratch, xfg_scratch_bytes(c->num_cu));
+    if (e != hipSuccess) { xfg_destroy(c); return hip_fail(e, "hipMalloc(scratch)"); }
     *out = c;
     return XFG_OK;
 }
@@ -89,6 +108,7 @@ extern "C" void xfg_destroy(xfg_ctx *c) {
     if (c->d_raw) (void)hipFree(c->d_raw);
     if (c->d_chunks) (void)hipFree(c->d_chunks);
     if (c->d_res) (void)hipFree(c->d_res);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -123,7 +143,8 @@ extern "C" int xfg_decode_device(xfg_ctx *c, const void *d_comp, size_t comp_len
     if (n > 0xffffffffull) return XFG_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    HIP_TRY(xfg_launch_inflate(d_comp, d_chunks, (uint32_t)n, d_raw, d_res, s));
+    // One launch at a time per context: the match-token scratch is per context.
+    HIP_TRY(xfg_launch_inflate(d_comp, d_chunks, (uint32_t)n, d_raw, d_res, c->d_scratch, c->num_cu, s));
     return XFG_OK;
 }
 

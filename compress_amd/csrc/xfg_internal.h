@@ -6,6 +6,8 @@
 #include <stdint.h>
 
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,
-                                         void *d_raw, void *d_res, hipStream_t stream);
+                                         void *d_raw, void *d_res, void *d_scratch,
+                                         int num_cu, hipStream_t stream);
+extern "C" size_t xfg_scratch_bytes(int num_cu);
 
 #endif
