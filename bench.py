@@ -35,6 +35,12 @@ WORKLOADS = {
     "c2": (16384, 65536, ("huffman", "repeats", "digits"), 6, 768),
     "c3": (16384, 262144, ("huffman", "repeats", "digits"), 6, 384),     # 4 GiB per GPU, 256 KiB chunks
     "small": (768, 65536, ("huffman", "repeats", "digits"), 6, 96),
+    # single-kind diagnostics (not bench lines): where does the time go per data shape
+    "huffman": (16384, 65536, ("huffman",), 6, 256),
+    "repeats": (16384, 65536, ("repeats",), 6, 256),
+    "digits": (16384, 65536, ("digits",), 6, 256),
+    "zeros": (16384, 65536, ("zeros",), 6, 4),
+    "random": (16384, 65536, ("random",), 6, 256),
 }
 
 

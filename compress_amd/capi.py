@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxflate_amd.so")
+# XFG_LIB selects another build of the same library (e.g. the diagnostic "make prof" build).
+LIB_PATH = os.environ.get("XFG_LIB") or os.path.join(_HERE, "lib", "libxflate_amd.so")
 
 # transport codes
 XFG_OK, XFG_E_ARG, XFG_E_HIP, XFG_E_NODEVICE, XFG_E_NOMEM, XFG_E_LIMIT = range(6)

@@ -1,8 +1,8 @@
 // inflate_kernel.hip -- DEFLATE inflate of independent XFLATE chunks on gfx950.
 //
 // One wavefront owns one chunk at a time.  A
-// workgroup is 4 independent waves; they share nothing and never barrier.  The
-// grid is persistent (3 workgroups per CU) and walks the chunk table round-robin.
+// workgroup is one wave.  The grid is persistent (as many workgroups as fit the
+// CUs' LDS) and walks the chunk table round-robin.
 //
 // Inside a Huffman block the 64 lanes decode 64 consecutive 512-bit segments of
 // the bit stream at once (decode_huffman_block):
@@ -47,7 +47,8 @@ typedef uint64_t u64;
 typedef int32_t i32;
 typedef int64_t i64;
 
-constexpr int WAVES_PER_BLOCK = 4;
+constexpr int WAVES_PER_BLOCK = 1;
+constexpr int BLOCKS_PER_CU = 5;         // LDS-bound: ~29.5 KiB per wave
 constexpr int LIT_ROOT = 10;            // first-level bits, literal/length table
 constexpr int DIST_ROOT = 8;            // first-level bits, distance table
 constexpr int CLEN_ROOT = 7;            // code-length code: max length 7, never needs sub-tables
@@ -59,7 +60,8 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 constexpr int SEG_BITS = 512;           // bits of compressed stream per lane and batch
 constexpr int BATCH_BYTES = 64 * SEG_BITS / 8;
 constexpr int BWIN_BYTES = BATCH_BYTES + 64;    // batch window: 16-byte alignment slack + 8-byte over-read
-constexpr int T_MAX = 64;               // match tokens per lane and batch (a lane stops its segment there)
+constexpr int OUT_LDS = 16384;          // bytes of batch output staged in LDS
+constexpr int T_MAX = 60;               // match tokens per lane and batch: 60*258 + 512 literals <= OUT_LDS
 constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix
 constexpr int SCRATCH_WORDS_PER_WAVE = T_MAX * 64;
 
@@ -107,6 +109,7 @@ struct WaveLds {
     u32 dist[DIST_TAB];
     u32 clen[CLEN_TAB];
     u64 win[BWIN_BYTES / 8];  // batch window; its first WIN_BYTES double as the header reader's ring
+    u64 out[OUT_LDS / 8];     // output of the current batch, flushed to HBM with coalesced stores
     u16 sorted[320];        // symbols in canonical (length, symbol) order
     u8  lens[320];          // code lengths: [0,hlit) literal/length, [hlit, hlit+hdist) distance
     u8  clens[32];          // code lengths of the code-length code
@@ -115,6 +118,22 @@ struct WaveLds {
     u32 offs[16];           // index in sorted[] of the first symbol of each length
     u32 endr[16];           // end of the length-l codes in ROOT-bit code space (l <= ROOT)
 };
+
+// ---- optional in-kernel profile (diagnostic build only: make prof) -------------
+// Cycle and event counters per phase, summed over all waves into a small global array
+// that no other code reads.  The production build compiles all of this away.
+enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
+       PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_N_ITERS, PF_N_TOKENS, PF_COUNTERS = 16 };
+#ifdef XFG_PROFILE
+__device__ unsigned long long g_prof[PF_COUNTERS];
+#define PROF_T0() const unsigned long long prof_t0_ = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(slot, lane_) do { if ((lane_) == 0) atomicAdd(&g_prof[slot], __builtin_amdgcn_s_memtime() - prof_t0_); } while (0)
+#define PROF_CNT(slot, v, lane_) do { if ((lane_) == 0) atomicAdd(&g_prof[slot], (unsigned long long)(v)); } while (0)
+#else
+#define PROF_T0() do {} while (0)
+#define PROF_ADD(slot, lane_) do {} while (0)
+#define PROF_CNT(slot, v, lane_) do {} while (0)
+#endif
 
 __device__ __forceinline__ void wave_sync() {
     // LDS operations of one wave execute in order; this only stops the compiler
@@ -376,37 +395,7 @@ struct Out {
     u8 *raw;            // this chunk's output
     u32 cap;            // raw_size
     u32 pos;            // bytes produced
-    u32 acked;          // every byte below this index is known to be visible to loads
 };
-
-__device__ __forceinline__ void make_visible(Out &o) {
-    // Stores of this wave reach L2 through the CU's own write-through L1; waiting for
-    // them (workgroup-scope release) is all a later load from the same CU needs.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    o.acked = o.pos;
-}
-
-// dictDecoder.TryWriteCopy/WriteCopy (flate/dict_decoder.go:86-132): forward copy with
-// byte-serial overlap semantics == periodic fill from the dist bytes before pos.
-__device__ __forceinline__ void match_copy(Out &o, u32 len, u32 dist, u32 lane) {
-    const u32 src = o.pos - dist;
-    const u32 src_end = dist >= len ? src + len : o.pos;
-    if (src_end > o.acked) make_visible(o);
-    if (dist >= len) {
-        for (u32 k = lane; k < len; k += 64) o.raw[o.pos + k] = o.raw[src + k];
-    } else if (dist == 1) {
-        const u8 b = o.raw[src];
-        for (u32 k = lane; k < len; k += 64) o.raw[o.pos + k] = b;
-    } else {
-        const u32 m = 0xffffffffu / dist + 1;                   // exact k / dist for k < 65536
-        for (u32 k = lane; k < len; k += 64) {
-            const u32 qk = __umulhi(k, m);
-            o.raw[o.pos + k] = o.raw[src + (k - qk * dist)];
-        }
-    }
-    o.pos += len;
-}
 
 // readRawData (flate/reader.go:137-159): n bytes from stream position sp to the output.
 __device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32 n, u32 lane) {
@@ -555,17 +544,18 @@ __device__ void load_batch_window(const Reader &r, WaveLds &L, i32 wb0, u32 lane
 }
 
 // Decode the tokens that START in [start, seg_end) (or until T_MAX matches).
-// EMIT = false: count only.  EMIT = true: literals go to raw[] at obase.., matches to mlist.
+// EMIT = false: count only.  EMIT = true: literals go to the LDS output window at orel..
+// (obase = the same position counted from the start of the chunk), matches to mlist.
 template <bool EMIT>
 __device__ __forceinline__ Seg decode_segment(const WaveLds &L, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
-                                              bool dist_empty, u8 *raw, u32 obase, u32 cap, u32 *mlist, u32 lane,
+                                              bool dist_empty, u8 *outw, u32 orel, u32 obase, u32 *mlist, u32 lane,
                                               u32 &err_out)
 {
     const u8 *win = reinterpret_cast<const u8 *>(L.win);
     u32 pos = start, nout = 0, nm = 0, flag = F_NONE, gap = 0;
     u32 guard = 0;
     while (pos < seg_end) {
-        if (++guard > (u32)SEG_BITS + 64) { flag = F_PANIC; break; }   // every token consumes >= 1 bit
+        if (++guard > 64u * SEG_BITS + 64) { flag = F_PANIC; break; }  // every token consumes >= 1 bit
         const u64 bits = lds_load64(win + ((i32)(pos >> 3) - wb0)) >> (pos & 7);    // >= 57 valid bits
         u32 e = L.lit[(u32)bits & ((1u << LIT_ROOT) - 1)];
         if (e_kind(e) == K_SUB)
@@ -574,7 +564,7 @@ __device__ __forceinline__ Seg decode_segment(const WaveLds &L, i32 wb0, u32 sta
         if (pos + n > total_bits) { flag = F_EOF; break; }
         const u32 kind = e_kind(e);
         if (kind == K_LIT) {
-            if (EMIT) { if (obase + nout < cap) raw[obase + nout] = (u8)e_val(e); }
+            if (EMIT) outw[orel + nout] = (u8)e_val(e);
             nout++; gap++;
             pos += n;
             continue;
@@ -624,6 +614,15 @@ __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 lane, u32 &total) {
     return incl - v;
 }
 
+__device__ __forceinline__ u32 wave_max(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u32 t = __shfl_xor(v, d);
+        v = t > v ? t : v;
+    }
+    return uni(v);
+}
+
 __device__ __forceinline__ void mem_sync() {
     // Make this wave's global stores visible to its own later loads: both go through the
     // CU's write-through L1, so waiting for the stores (workgroup-scope release) suffices.
@@ -631,62 +630,121 @@ __device__ __forceinline__ void mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// Copy n bytes from raw[s..] to raw[d..], ranges disjoint, any alignment.
-__device__ __forceinline__ void copy_disjoint(u8 *raw, u32 d, u32 s, u32 n) {
+// n bytes global -> LDS, any alignment.
+__device__ __forceinline__ void copy_g2l(u8 *dst, const u8 *src, u32 n) {
     u32 j = 0;
     for (; j + 16 <= n; j += 16) {
         u64 a, b2;
-        __builtin_memcpy(&a, raw + s + j, 8);
-        __builtin_memcpy(&b2, raw + s + j + 8, 8);
-        __builtin_memcpy(raw + d + j, &a, 8);
-        __builtin_memcpy(raw + d + j + 8, &b2, 8);
+        __builtin_memcpy(&a, src + j, 8);
+        __builtin_memcpy(&b2, src + j + 8, 8);
+        __builtin_memcpy(dst + j, &a, 8);
+        __builtin_memcpy(dst + j + 8, &b2, 8);
     }
     if (j + 8 <= n) {
         u64 a;
-        __builtin_memcpy(&a, raw + s + j, 8);
-        __builtin_memcpy(raw + d + j, &a, 8);
+        __builtin_memcpy(&a, src + j, 8);
+        __builtin_memcpy(dst + j, &a, 8);
         j += 8;
     }
-    for (; j < n; j++) raw[d + j] = raw[s + j];
+    for (; j < n; j++) dst[j] = src[j];
+}
+// n bytes LDS -> LDS, ranges disjoint, any alignment.
+__device__ __forceinline__ void copy_l2l(u8 *dst, const u8 *src, u32 n) {
+    u32 j = 0;
+    for (; j + 8 <= n; j += 8) {
+        u64 a;
+        __builtin_memcpy(&a, src + j, 8);
+        __builtin_memcpy(dst + j, &a, 8);
+    }
+    for (; j < n; j++) dst[j] = src[j];
 }
 
-// Stage 2: resolve the match tokens of one batch.  Lane i owns the tokens of segment i in
-// order; my_base is where its output starts.  All literals of the batch are already in place.
-__device__ void resolve_matches(u8 *raw, u32 cap, const u32 *mlist, u32 nm, u32 my_base, u32 lane) {
-    u32 k = 0, cur = my_base;
-    u32 dst = 0, src = 0, rem = 0;
-    bool loaded = false;
-    for (u32 round = 0; round < 64u * T_MAX * 10u; round++) {   // each round retires >= 1 copy step
-        const bool have = k < nm;
-        if (have && !loaded) {
-            const u32 m = mlist[k * 64 + lane];
-            const u32 len = (m & 255) + 3, dist = ((m >> 8) & 32767) + 1, gap = m >> 23;
-            dst = cur + gap;
-            src = dst - dist;
-            rem = len;
-            loaded = true;
-        }
-        const u64 pending = __ballot(have);
-        if (pending == 0) break;
-        // Everything below the destination of the earliest unresolved match is final.
-        const u32 first = (u32)__ffsll((long long)pending) - 1;
-        const u32 water = uni(__shfl(dst, first));
-        if (have) {
-            // This round copies at most the part of the source that is final now: for an
-            // overlapping match (dist < len) that is dist bytes, and the period doubles per round.
-            u32 n = dst - src;
-            if (n > rem) n = rem;
-            const bool ready = (src + n <= water) || (src >= my_base);
-            if (ready) {
-                u32 cn = n;
-                if (dst >= cap) cn = 0; else if (cn > cap - dst) cn = cap - dst;
-                copy_disjoint(raw, dst, src, cn);
-                dst += n; rem -= n;
-                if (rem == 0) { cur = dst; k++; loaded = false; }
+// Stage 2: resolve the match tokens of one batch inside the LDS output window.
+//   raw/base   the chunk's output so far: bytes [0, base) are final in HBM
+//   outw       the batch's bytes [base, base + total) live at outw[0, total); literals are in place
+//   my_rel     where this lane's tokens start in outw
+// Pass A copies every match whose source lies entirely before `base` (HBM -> LDS, no
+// dependencies).  Pass B runs rounds over the rest: a match is ready when its source is
+// below the watermark (the destination of the earliest unresolved match) or inside the
+// lane's own finished part; overlapping matches double their period each round.
+__device__ void resolve_matches(const u8 *raw, u32 base, u8 *outw, const u32 *mlist, u32 nm, u32 my_rel, u32 lane) {
+    // ---- pass A: sources before the batch
+    const u32 max_nm = wave_max(nm);
+    {
+        u32 cur = my_rel;
+        for (u32 k = 0; k < max_nm; k++) {
+            if (k < nm) {
+                const u32 m = mlist[k * 64 + lane];
+                const u32 len = (m & 255) + 3, dist = ((m >> 8) & 32767) + 1, gap = m >> 23;
+                const u32 dst = cur + gap;
+                if (dist >= dst + len)                          // src + len <= base  <=>  dist - dst >= len
+                    copy_g2l(outw + dst, raw + (base + dst - dist), len);
+                cur = dst + len;
             }
         }
-        mem_sync();
     }
+    wave_sync();
+    // ---- pass B: sources inside the batch (or straddling its start)
+    u32 k = 0, cur = my_rel;
+    u32 dst = 0, dist = 0, rem = 0, span = 0;
+    bool loaded = false;
+    u32 round = 0;
+    for (; round < 64u * T_MAX * 12u; round++) {                // each round retires >= 1 copy step
+        while (k < nm && !loaded) {
+            const u32 m = mlist[k * 64 + lane];
+            const u32 len = (m & 255) + 3, gap = m >> 23;
+            dist = ((m >> 8) & 32767) + 1;
+            dst = cur + gap;
+            if (dist >= dst + len) { cur = dst + len; k++; continue; }     // done in pass A
+            rem = len;
+            span = dist;
+            loaded = true;
+        }
+        const bool have = k < nm;
+        const u64 pending = __ballot(have);
+        if (pending == 0) break;
+        const u32 first = (u32)__ffsll((long long)pending) - 1;
+        const u32 water = uni(__shfl(dst, first));               // everything below is final
+        if (have) {
+            if (dist > dst) {
+                // The source starts before the batch: bytes [base+dst-dist, base) come from HBM.
+                u32 n = dist - dst;
+                if (n > rem) n = rem;
+                copy_g2l(outw + dst, raw + (base + dst - dist), n);
+                dst += n; rem -= n;
+            } else {
+                // out[dst + j] = out[dst + j - span]: span is a multiple of dist that doubles every time a
+                // whole span has been copied, so an overlapping match needs log2(len / dist) rounds.
+                const u32 src = dst - span;
+                const u32 n = span < rem ? span : rem;
+                const bool ready = (src + n <= water) || (src >= my_rel);
+                if (ready) {
+                    copy_l2l(outw + dst, outw + src, n);
+                    dst += n; rem -= n;
+                    if (n == span) span *= 2;
+                }
+            }
+            if (rem == 0) { cur = dst; k++; loaded = false; }
+        }
+        wave_sync();
+    }
+    PROF_CNT(PF_N_ROUNDS, round, lane);
+}
+
+// Flush outw[0, n) to raw[base, base + n), coalesced 16-byte stores where the HBM address allows.
+__device__ void flush_output(u8 *raw, u32 base, const u8 *outw, u32 n, u32 lane) {
+    u8 *g = raw + base;
+    u32 head = (u32)((16 - ((uintptr_t)g & 15)) & 15);
+    if (head > n) head = n;
+    if (lane < head) g[lane] = outw[lane];
+    const u32 body = (n - head) >> 4;
+    for (u32 i = lane; i < body; i += 64) {
+        uint4 v;
+        __builtin_memcpy(&v, outw + head + i * 16, 16);
+        *reinterpret_cast<uint4 *>(g + head + i * 16) = v;
+    }
+    const u32 done = head + body * 16;
+    if (done + lane < n) g[done + lane] = outw[done + lane];
 }
 
 struct BlockEnd {
@@ -707,9 +765,15 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         // ---- compressed window of this batch
         const i64 abs0 = (i64)(r.base_al + r.lead) + (p0 >> 3);
         const i32 wb0 = (i32)((abs0 & ~(i64)15) - (i64)(r.base_al + r.lead));
-        wave_sync();
-        load_batch_window(r, L, wb0, lane);
-        wave_sync();
+        {
+            PROF_T0();
+            wave_sync();
+            load_batch_window(r, L, wb0, lane);
+            wave_sync();
+            PROF_ADD(PF_WINDOW, lane);
+        }
+        PROF_CNT(PF_N_BATCH, 1, lane);
+        PROF_T0();
 
         // ---- stage 1a: speculative passes until the chain of segment starts is stable
         u32 start = p0 + lane * SEG_BITS;
@@ -722,6 +786,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         for (int pass = 1;; pass++) {
             if (dirty && !dead)
                 sg = decode_segment<false>(L, wb0, start, seg_end, total_bits, dist_empty, nullptr, 0, 0, nullptr, lane, dummy);
+            PROF_CNT(PF_N_PASS, 1, lane);
             const u32 pe = __shfl_up(sg.end, 1);
             const u32 pf = __shfl_up(sg.flag, 1);
             const u32 pd = __shfl_up((u32)dead, 1);
@@ -736,44 +801,71 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
             if ((pass >= 2 && fd >= 40) || pass >= MAX_PASSES) { verified = fd; break; }
         }
+        PROF_ADD(PF_COUNT, lane);
         const bool live = !dead && lane < verified;
         const u64 lm = __ballot(live);
         const u32 nlive = (u32)__popcll(lm);                      // live lanes are 0 .. nlive-1
-        const u32 lastl = nlive - 1;
 
-        // ---- output offsets
+        // ---- output offsets; keep the prefix of lanes whose output fits the LDS window
         u32 total_out;
-        const u32 rel = wave_excl_scan(live ? sg.nout : 0, lane, total_out);
-        const u32 my_base = o.pos + rel;
+        u32 rel = wave_excl_scan(live ? sg.nout : 0, lane, total_out);
+        bool keep = live && (rel + sg.nout <= (u32)OUT_LDS);
+        const u64 km = __ballot(keep);
+        // kept lanes must be a prefix: cut at the first live lane that does not fit
+        const u64 cut = lm & ~km;
+        u32 nkeep = nlive;
+        if (cut) nkeep = (u32)__ffsll((long long)cut) - 1;       // >= 1: one lane's output always fits
+        keep = lane < nkeep;
+        rel = wave_excl_scan(keep ? sg.nout : 0, lane, total_out);
+        const u32 lastl = nkeep - 1;
+        PROF_CNT(PF_N_LIVE, nkeep, lane);
+        u8 *outw = reinterpret_cast<u8 *>(L.out);
 
-        // ---- stage 1b: final pass, literals to their places, matches to the token list
+        // ---- stage 1b: final pass, literals into the output window, matches to the token list
         u32 err_out = 0;
         Seg fin = sg;
-        if (live)
-            fin = decode_segment<true>(L, wb0, start, seg_end, total_bits, dist_empty, o.raw, my_base, o.cap, mlist, lane, err_out);
-        mem_sync();
+        {
+            PROF_T0();
+            if (keep)
+                fin = decode_segment<true>(L, wb0, start, seg_end, total_bits, dist_empty, outw, rel, o.pos + rel, mlist, lane, err_out);
+            mem_sync();                                         // token list: written and read back by the same lane
+            PROF_ADD(PF_EMIT, lane);
+        }
 
         // A distance beyond the history ends the chunk at that token (flate/reader.go:223-225).
-        const u64 em = __ballot(live && fin.flag == F_DIST);
-        u32 nm = live ? fin.nmatch : 0;
+        const u64 em = __ballot(keep && fin.flag == F_DIST);
+        u32 nm = keep ? fin.nmatch : 0;
         u32 elane = 64;
         if (em) {
             elane = (u32)__ffsll((long long)em) - 1;
             if (lane > elane) nm = 0;                            // tokens after the error do not exist
+            total_out = uni(__shfl(rel + err_out, elane));
         }
         // ---- stage 2
-        resolve_matches(o.raw, o.cap, mlist, nm, my_base, lane);
+        {
+            PROF_T0();
+            resolve_matches(o.raw, o.pos, outw, mlist, nm, rel, lane);
+            PROF_ADD(PF_RESOLVE, lane);
+        }
+        // ---- flush to HBM (never beyond the chunk's capacity)
+        {
+            u32 nflush = total_out;
+            if (o.pos >= o.cap) nflush = 0; else if (nflush > o.cap - o.pos) nflush = o.cap - o.pos;
+            wave_sync();
+            flush_output(o.raw, o.pos, outw, nflush, lane);
+            mem_sync();                                         // later batches read these bytes back
+        }
 
         if (em) {
             be.status = XFG_ST_CORRUPTED;
             be.bitpos = uni(__shfl(fin.end, elane));
-            o.pos = uni(__shfl(my_base + err_out, elane));
+            o.pos += total_out;
             if (o.pos > o.cap) { o.pos = o.cap; be.status = XFG_ST_OUT_FULL; }
             return be;
         }
         const u32 lflag = uni(__shfl(sg.flag, lastl));
         const u32 lend = uni(__shfl(sg.end, lastl));
-        if (o.pos + total_out > o.cap || total_out > o.cap) {      // more output than the chunk may hold
+        if (total_out > o.cap - o.pos) {                         // more output than the chunk may hold
             o.pos = o.cap;
             be.status = XFG_ST_OUT_FULL;
             be.bitpos = lend;
@@ -793,6 +885,7 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
                               u8 *__restrict__ raw, xfg_result *__restrict__ res,
                               WaveLds &L, u32 lane, u32 *mlist)
 {
+    PROF_T0();
     xfg_chunk c = chunks[ci];
     c.comp_off = uni64(c.comp_off);
     c.raw_off = uni64(c.raw_off);
@@ -815,7 +908,6 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
     o.raw = raw + c.raw_off;
     o.cap = uni((u32)c.raw_size);
     o.pos = 0;
-    o.acked = 0;
 
     const bool rfc_rep16 = (flags & XFG_CHUNK_RFC_REP16) != 0;
     int status;
@@ -846,7 +938,12 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
             bool eof = false, full = false;
             if (take > r.total - sp) { take = r.total - sp; eof = true; }
             if (take > o.cap - o.pos) { take = o.cap - o.pos; full = true; eof = false; }
-            stored_copy(r, o, sp, take, lane);
+            {
+                PROF_T0();
+                stored_copy(r, o, sp, take, lane);
+                mem_sync();                                     // a later block may copy from these bytes
+                PROF_ADD(PF_STORED, lane);
+            }
             r.bytepos = sp + take;
             r.bitbuf = 0;
             r.bitcnt = 0;
@@ -862,9 +959,12 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
                 tables = 1;
             } else {
                 tables = 2;
+                PROF_T0();
                 status = read_dynamic_header(r, L, lane, rfc_rep16, lit_state, dist_state);
+                PROF_ADD(PF_HEADER, lane);
                 if (status != XFG_ST_OK) break;
             }
+            PROF_CNT(PF_N_BLOCKS, 1, lane);
             const BlockEnd be = decode_huffman_block(r, o, L, lane, reader_bitpos(r), lit_state, dist_state, mlist);
             wave_sync();
             reader_seek(r, be.bitpos);                          // the window was reused by the block decoder
@@ -897,6 +997,7 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
     } else if (status == XFG_ST_OUT_FULL && (flags & XFG_CHUNK_VERIFY)) {
         status = XFG_ST_SIZE_MISMATCH;                          // more output than the index promised
     }
+    PROF_ADD(PF_TOTAL, lane);
     if (lane == 0) {
         xfg_result out;
         out.status = status;
@@ -927,17 +1028,30 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
 
 } // namespace xfg
 
+#ifdef XFG_PROFILE
+// Diagnostic build only: read and clear the in-kernel profile counters.
+extern "C" int xfg_debug_profile(unsigned long long *out, int n)
+{
+    unsigned long long h[xfg::PF_COUNTERS];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(xfg::g_prof), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < xfg::PF_COUNTERS; i++) out[i] = h[i];
+    unsigned long long z[xfg::PF_COUNTERS] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(xfg::g_prof), z, sizeof z) != hipSuccess) return -1;
+    return xfg::PF_COUNTERS;
+}
+#endif
+
 extern "C" uint32_t xfg_grid_blocks(uint32_t n, int num_cu)
 {
-    // 3 workgroups of 4 waves fit one CU (LDS-bound, ~52 KiB each).
+    // BLOCKS_PER_CU single-wave workgroups fit one CU (LDS-bound).
     uint32_t want = (n + xfg::WAVES_PER_BLOCK - 1) / xfg::WAVES_PER_BLOCK;
-    uint32_t cap = (uint32_t)num_cu * 3u;
+    uint32_t cap = (uint32_t)num_cu * (uint32_t)xfg::BLOCKS_PER_CU;
     return want < cap ? want : cap;
 }
 
 extern "C" size_t xfg_scratch_bytes(int num_cu)
 {
-    return (size_t)num_cu * 3u * xfg::WAVES_PER_BLOCK * xfg::SCRATCH_WORDS_PER_WAVE * sizeof(uint32_t);
+    return (size_t)num_cu * xfg::BLOCKS_PER_CU * xfg::WAVES_PER_BLOCK * xfg::SCRATCH_WORDS_PER_WAVE * sizeof(uint32_t);
 }
 
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,

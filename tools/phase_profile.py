@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where does a chunk's time go?  Runs one decode of a bench workload on the diagnostic build
+(make -C compress_amd/csrc prof; XFG_LIB=compress_amd/lib/libxflate_amd_prof.so) and prints the
+in-kernel phase counters (wave-cycles summed over all waves, and event counts)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("XFG_LIB", os.path.join(ROOT, "compress_amd", "lib", "libxflate_amd_prof.so"))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from compress_amd import capi  # noqa: E402
+
+NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "total",
+         "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "n_iters", "n_tokens"]
+
+
+def main():
+    for w in sys.argv[1:] or ["c2"]:
+        shard = bench.build_shard(w, 0)
+        dev = torch.device("cuda", 0)
+        ctx = capi.Context(0)
+        n = shard["n"]
+        d_comp = torch.frombuffer(bytearray(shard["comp"]) + bytearray(64), dtype=torch.uint8).to(dev)
+        d_chunks = torch.frombuffer(bytearray(bytes(shard["descs"])), dtype=torch.uint8).to(dev)
+        d_raw = torch.zeros(shard["raw_len"] + 64, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
+        L = capi.lib()
+        buf = (ctypes.c_ulonglong * 16)()
+        for it in range(2):
+            L.xfg_debug_profile(buf, 16)          # clear
+            ctx.decode_device(d_comp.data_ptr(), len(shard["comp"]), d_chunks.data_ptr(), n,
+                              d_raw.data_ptr(), shard["raw_len"], d_res.data_ptr(), None)
+            ctx.sync()
+        L.xfg_debug_profile(buf, 16)
+        v = {k: buf[i] for i, k in enumerate(NAMES)}
+        tot = max(v["total"], 1)
+        print("== %s: %d chunks" % (w, n))
+        for k in NAMES[:7]:
+            print("  %-13s %14d wave-cycles  %5.1f %%" % (k, v[k], 100.0 * v[k] / tot))
+        nb = max(v["n_batch"], 1)
+        print("  batches %d  passes/batch %.2f  live lanes/batch %.1f  rounds/batch %.1f  blocks %d" %
+              (v["n_batch"], v["n_pass"] / nb, v["n_live_lanes"] / nb, v["n_rounds"] / nb, v["n_blocks"]))
+        print("  cycles/batch: count %.0f emit %.0f resolve %.0f window %.0f; header cycles/block %.0f" %
+              (v["count_passes"] / nb, v["emit_pass"] / nb, v["resolve"] / nb, v["window"] / nb,
+               v["header"] / max(v["n_blocks"], 1)))
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()
