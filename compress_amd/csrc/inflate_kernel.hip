@@ -48,7 +48,7 @@ typedef int32_t i32;
 typedef int64_t i64;
 
 constexpr int WAVES_PER_BLOCK = 1;
-constexpr int BLOCKS_PER_CU = 5;         // LDS-bound: ~29.5 KiB per wave
+constexpr int MAX_BLOCKS_PER_CU = 16;    // upper bound used to size the scratch; the real number comes from the occupancy query
 constexpr int LIT_ROOT = 10;            // first-level bits, literal/length table
 constexpr int DIST_ROOT = 8;            // first-level bits, distance table
 constexpr int CLEN_ROOT = 7;            // code-length code: max length 7, never needs sub-tables
@@ -57,11 +57,17 @@ constexpr int DIST_TAB = 416;           // >= enough(30, 8, 15)  = 402 entries
 constexpr int CLEN_TAB = 128;
 constexpr int WIN_BYTES = 1024;         // header reader's window: two 512-byte halves
 constexpr int MAX_HIST = 32768;         // flate/common.go:16
-constexpr int SEG_BITS = 512;           // bits of compressed stream per lane and batch
+#ifndef XFG_SEG_BITS
+#define XFG_SEG_BITS 512
+#endif
+#ifndef XFG_OUT_LDS
+#define XFG_OUT_LDS 16384
+#endif
+constexpr int SEG_BITS = XFG_SEG_BITS;  // bits of compressed stream per lane and batch
 constexpr int BATCH_BYTES = 64 * SEG_BITS / 8;
-constexpr int BWIN_BYTES = BATCH_BYTES + 64;    // batch window: 16-byte alignment slack + 8-byte over-read
-constexpr int OUT_LDS = 16384;          // bytes of batch output staged in LDS
-constexpr int T_MAX = 60;               // match tokens per lane and batch: 60*258 + 512 literals <= OUT_LDS
+constexpr int BWIN_BYTES = (BATCH_BYTES + 64) > 1024 ? (BATCH_BYTES + 64) : 1024;   // batch window: 16-byte alignment slack + 8-byte over-read; >= the header ring
+constexpr int OUT_LDS = XFG_OUT_LDS;    // bytes of batch output staged in LDS
+constexpr int T_MAX = (OUT_LDS - SEG_BITS) / 258;   // match tokens per lane and batch: T_MAX*258 + SEG_BITS literals <= OUT_LDS
 constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix
 constexpr int SCRATCH_WORDS_PER_WAVE = T_MAX * 64;
 
@@ -1041,17 +1047,30 @@ extern "C" int xfg_debug_profile(unsigned long long *out, int n)
 }
 #endif
 
+static int blocks_per_cu()
+{
+    static int cached = 0;
+    if (cached == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_kernel, 64 * xfg::WAVES_PER_BLOCK, 0) != hipSuccess || nb < 1)
+            nb = 1;
+        if (nb > xfg::MAX_BLOCKS_PER_CU) nb = xfg::MAX_BLOCKS_PER_CU;
+        cached = nb;
+    }
+    return cached;
+}
+
 extern "C" uint32_t xfg_grid_blocks(uint32_t n, int num_cu)
 {
-    // BLOCKS_PER_CU single-wave workgroups fit one CU (LDS-bound).
+    // Persistent grid: as many single-wave workgroups as the CUs can hold (LDS-bound).
     uint32_t want = (n + xfg::WAVES_PER_BLOCK - 1) / xfg::WAVES_PER_BLOCK;
-    uint32_t cap = (uint32_t)num_cu * (uint32_t)xfg::BLOCKS_PER_CU;
+    uint32_t cap = (uint32_t)num_cu * (uint32_t)blocks_per_cu();
     return want < cap ? want : cap;
 }
 
 extern "C" size_t xfg_scratch_bytes(int num_cu)
 {
-    return (size_t)num_cu * xfg::BLOCKS_PER_CU * xfg::WAVES_PER_BLOCK * xfg::SCRATCH_WORDS_PER_WAVE * sizeof(uint32_t);
+    return (size_t)num_cu * xfg::MAX_BLOCKS_PER_CU * xfg::WAVES_PER_BLOCK * xfg::SCRATCH_WORDS_PER_WAVE * sizeof(uint32_t);
 }
 
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,
