@@ -4,19 +4,26 @@
 // workgroup is one wave.  The grid is persistent (as many workgroups as fit the
 // CUs' LDS) and walks the chunk table round-robin.
 //
-// Inside a Huffman block the 64 lanes decode 64 consecutive 512-bit segments of
-// the bit stream at once (decode_huffman_block):
+// Inside a Huffman block the 64 lanes decode 64 consecutive SEG_BITS-bit segments
+// of the bit stream at once (decode_huffman_block), one "batch" per iteration:
 //   stage 1  speculative decode: lane i starts at segment boundary i, which is
 //            almost never a code-word boundary; prefix codes self-synchronise, so
 //            its END position is usually right anyway.  Lanes then restart from
 //            their predecessor's end until the chain of starts is stable; the
 //            stable prefix of lanes is exactly the serial decoder's token stream.
-//            A last pass writes literals to their final positions (offsets from a
-//            wave prefix sum of bytes per lane) and emits match tokens.
-//   stage 2  match resolution: every lane copies its own matches; a match is
-//            ready when all of its source bytes are final, which is tracked with
-//            a wave-wide watermark.  Overlapping matches double their period per
-//            round, so no copy ever reads bytes written in the same round.
+//            Every lane runs one table lookup per loop iteration (literal/length
+//            root, distance root and second-level tables share the instruction:
+//            a small per-lane state machine), from a 64-bit register bit buffer
+//            that is topped up from the LDS copy of the compressed window.
+//            A last pass writes literals to their final positions in an LDS
+//            output window (offsets from a wave prefix sum of bytes per lane)
+//            and appends match tokens to a compact token list in LDS.
+//   stage 2  match resolution, round-major: 64 consecutive tokens per round, one
+//            per lane.  Sources before the window come from HBM/L2 (all lanes'
+//            loads in flight together); sources inside the window are ready once
+//            they lie below the destination of the first unresolved token of the
+//            round.  Overlapping matches double their period per step.  The
+//            window is then flushed to HBM with coalesced 16-byte stores.
 //
 // What this restates, in the reference's terms (all under /root/reference):
 //   chunkReader            xflate/reader.go:32-70      -> win_load(): chunk || 01 00 00 ff ff is a virtual stream
@@ -26,10 +33,10 @@
 //   GeneratePrefixes       internal/prefix/prefix.go:326-384 -> build_table() steps 1-3 (histogram, Kraft, canonical rank)
 //   Decoder.Init           internal/prefix/decoder.go:51-136 -> build_table() steps 4-5 (root table + sub-tables in LDS)
 //   readBlock              flate/reader.go:162-250     -> decode_huffman_block() / decode_segment()
-//   dictDecoder            flate/dict_decoder.go:86-132 -> resolve_matches(): the output buffer is the window
+//   dictDecoder            flate/dict_decoder.go:86-132 -> resolve_tokens(): the output buffer is the window
 //   Read's post-chunk checks xflate/reader.go:186-202  -> epilogue of inflate_chunk()
 //
-// The decode state (bit buffer, positions, table entries) is wave-uniform and
+// The block-header state (bit buffer, positions, table entries) is wave-uniform and
 // kept in SGPRs via readfirstlane; the 64 lanes cooperate on everything that
 // has width: coalesced refill of the compressed window into LDS, table
 // construction, stored-block and match copies.
@@ -48,7 +55,7 @@ typedef int32_t i32;
 typedef int64_t i64;
 
 constexpr int WAVES_PER_BLOCK = 1;
-constexpr int MAX_BLOCKS_PER_CU = 16;    // upper bound used to size the scratch; the real number comes from the occupancy query
+constexpr int MAX_BLOCKS_PER_CU = 32;    // hardware limit of waves per CU; the real number comes from the occupancy query
 constexpr int LIT_ROOT = 10;            // first-level bits, literal/length table
 constexpr int DIST_ROOT = 8;            // first-level bits, distance table
 constexpr int CLEN_ROOT = 7;            // code-length code: max length 7, never needs sub-tables
@@ -58,18 +65,25 @@ constexpr int CLEN_TAB = 128;
 constexpr int WIN_BYTES = 1024;         // header reader's window: two 512-byte halves
 constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_SEG_BITS
-#define XFG_SEG_BITS 512
+#define XFG_SEG_BITS 256
 #endif
 #ifndef XFG_OUT_LDS
-#define XFG_OUT_LDS 16384
+#define XFG_OUT_LDS 8192
+#endif
+#ifndef XFG_TOK_MAX
+#define XFG_TOK_MAX 768
 #endif
 constexpr int SEG_BITS = XFG_SEG_BITS;  // bits of compressed stream per lane and batch
 constexpr int BATCH_BYTES = 64 * SEG_BITS / 8;
-constexpr int BWIN_BYTES = (BATCH_BYTES + 64) > 1024 ? (BATCH_BYTES + 64) : 1024;   // batch window: 16-byte alignment slack + 8-byte over-read; >= the header ring
+constexpr int BWIN_BYTES = (BATCH_BYTES + 64) > 1024 ? (BATCH_BYTES + 64) : 1024;   // batch window: 16-byte alignment slack + over-read; >= the header ring
+constexpr int NPF = (BWIN_BYTES + 1023) / 1024;     // 16-byte units per lane that cover the batch window
 constexpr int OUT_LDS = XFG_OUT_LDS;    // bytes of batch output staged in LDS
-constexpr int T_MAX = (OUT_LDS - SEG_BITS) / 258;   // match tokens per lane and batch: T_MAX*258 + SEG_BITS literals <= OUT_LDS
+constexpr int OUT_CAP = OUT_LDS - SEG_BITS - 258;   // a lane stops after the match that takes it to OUT_CAP: one lane always fits
+constexpr int TOK_MAX = XFG_TOK_MAX;    // match tokens per batch
 constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix
-constexpr int SCRATCH_WORDS_PER_WAVE = T_MAX * 64;
+static_assert(OUT_CAP >= 1024, "output window too small");
+static_assert(TOK_MAX >= SEG_BITS / 2, "one lane's tokens (>= 2 bits each) must fit the token list");
+static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
 
 // Table entry (u32):
 //   [4:0]   bits to consume for this code word (total code length, sub-table entries included)
@@ -109,13 +123,10 @@ __device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
     }
 }
 
-// Per-wave LDS.  ~9.6 KiB -> 16 waves per CU.
-struct WaveLds {
-    u32 lit[LIT_TAB];
-    u32 dist[DIST_TAB];
-    u32 clen[CLEN_TAB];
-    u64 win[BWIN_BYTES / 8];  // batch window; its first WIN_BYTES double as the header reader's ring
-    u64 out[OUT_LDS / 8];     // output of the current batch, flushed to HBM with coalesced stores
+// Per-wave LDS.  The header scratch is live only while a block header is parsed and its
+// tables are built; the output window is live only while a block's tokens are decoded.
+struct HeaderScratch {
+    u32 clen[CLEN_TAB];     // decode table of the code-length code
     u16 sorted[320];        // symbols in canonical (length, symbol) order
     u8  lens[320];          // code lengths: [0,hlit) literal/length, [hlit, hlit+hdist) distance
     u8  clens[32];          // code lengths of the code-length code
@@ -124,12 +135,23 @@ struct WaveLds {
     u32 offs[16];           // index in sorted[] of the first symbol of each length
     u32 endr[16];           // end of the length-l codes in ROOT-bit code space (l <= ROOT)
 };
+struct WaveLds {
+    u32 tab[LIT_TAB + DIST_TAB];    // literal/length table at 0, distance table at LIT_TAB
+    u64 win[BWIN_BYTES / 8];        // batch window; its first WIN_BYTES double as the header reader's ring
+    union {
+        u64 out[OUT_LDS / 8];       // output of the current batch, flushed to HBM with coalesced stores
+        HeaderScratch h;
+    };
+    u32 tok[TOK_MAX];               // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
+    u16 tdst[TOK_MAX];              // their destinations in the output window
+};
+static_assert(sizeof(HeaderScratch) <= OUT_LDS, "header scratch must fit the output window");
 
 // ---- optional in-kernel profile (diagnostic build only: make prof) -------------
 // Cycle and event counters per phase, summed over all waves into a small global array
 // that no other code reads.  The production build compiles all of this away.
 enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
-       PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_N_ITERS, PF_N_TOKENS, PF_COUNTERS = 16 };
+       PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS, PF_COUNTERS = 16 };
 #ifdef XFG_PROFILE
 __device__ unsigned long long g_prof[PF_COUNTERS];
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_amdgcn_s_memtime()
@@ -262,14 +284,14 @@ __device__ __forceinline__ u32 reader_bitpos(const Reader &r) { return r.bytepos
 // Returns 0 = ok, 1 = empty code (decode with it is an error), 2 = invalid
 // (over/under-subscribed: GeneratePrefixes errors, prefix.go:355-369).
 // ---------------------------------------------------------------------------
-template <int TYPE, int ROOT>
+template <int TYPE, int ROOT, int TAB_OFF>
 __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane) {
     // 1. histogram of code lengths
-    if (lane < 16) L.cnt[lane] = 0;
+    if (lane < 16) L.h.cnt[lane] = 0;
     wave_sync();
     for (u32 i = lane; i < n; i += 64) {
         const u32 l = lens[i];
-        if (l) atomicAdd(&L.cnt[l], 1u);
+        if (l) atomicAdd(&L.h.cnt[l], 1u);
     }
     wave_sync();
 
@@ -278,7 +300,7 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
     u32 nz = 0, maxlen = 0;
 #pragma unroll
     for (int l = 1; l <= 15; l++) {
-        cnt[l] = uni(L.cnt[l]);
+        cnt[l] = uni(L.h.cnt[l]);
         nz += cnt[l];
         if (cnt[l]) maxlen = l;
     }
@@ -308,10 +330,10 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
             code <<= 1;
             run[l] = off;
             if (lane == 0) {
-                L.first[l] = code;
-                L.offs[l] = off;
-                L.cnt[l] = cnt[l];
-                if (l <= ROOT) L.endr[l] = (code + cnt[l]) << (ROOT - l);
+                L.h.first[l] = code;
+                L.h.offs[l] = off;
+                L.h.cnt[l] = cnt[l];
+                if (l <= ROOT) L.h.endr[l] = (code + cnt[l]) << (ROOT - l);
             }
             code += cnt[l];
             off += cnt[l];
@@ -326,22 +348,22 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
         for (int q = 1; q <= 15; q++) {
             if (cnt[q] == 0) continue;
             const u64 m = __ballot(l == (u32)q);
-            if (l == (u32)q) L.sorted[run[q] + __popcll(m & ((1ull << lane) - 1))] = (u16)i;
+            if (l == (u32)q) L.h.sorted[run[q] + __popcll(m & ((1ull << lane) - 1))] = (u16)i;
             run[q] += __popcll(m);
         }
     }
-    if (degenerate && lane == 0) L.sorted[1] = 0xffff;          // the out-of-range sibling
+    if (degenerate && lane == 0) L.h.sorted[1] = 0xffff;          // the out-of-range sibling
     wave_sync();
 
     // 4. root table.  u runs over ROOT-bit code space MSB-first; the table is indexed LSB-first.
     //    Codes of length l <= ROOT own [endr[l-1], endr[l]) there; whatever lies at or beyond
     //    end_root is the prefix of a longer code.
     const u32 lim = maxlen < (u32)ROOT ? maxlen : (u32)ROOT;
-    const u32 end_root = uni(L.endr[lim]);
+    const u32 end_root = uni(L.h.endr[lim]);
     for (u32 u = lane; u < end_root; u += 64) {
         u32 l = 1;
-        while (l < (u32)ROOT && u >= L.endr[l]) l++;
-        const u32 sym = L.sorted[L.offs[l] + (u >> (ROOT - l)) - L.first[l]];
+        while (l < (u32)ROOT && u >= L.h.endr[l]) l++;
+        const u32 sym = L.h.sorted[L.h.offs[l] + (u >> (ROOT - l)) - L.h.first[l]];
         tab[__brev(u) >> (32 - ROOT)] = sym_entry(TYPE, sym, l);
     }
 
@@ -355,9 +377,9 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
             u32 sb = 0;
             if (act) {
                 for (u32 l = maxlen; l > (u32)ROOT; l--) {
-                    const u32 c = L.cnt[l];
+                    const u32 c = L.h.cnt[l];
                     if (!c) continue;
-                    const u32 f = L.first[l];
+                    const u32 f = L.h.first[l];
                     const u32 lo = u << (l - ROOT), hi = (u + 1) << (l - ROOT);
                     if (lo < f + c && hi > f) { sb = l - ROOT; break; }
                 }
@@ -373,12 +395,12 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
             const u32 my_off = next + incl - size;
             next += uni(__shfl(incl, 63));
             if (act) {
-                tab[__brev(u) >> (32 - ROOT)] = mk_entry(0, K_SUB, sb, my_off);
+                tab[__brev(u) >> (32 - ROOT)] = mk_entry(0, K_SUB, sb, my_off + TAB_OFF);   // offset in WaveLds::tab
                 for (u32 v = 0; v < (1u << sb); v++) {
                     const u32 w = (u << sb) | v;                // (ROOT+sb)-bit code space, MSB-first
                     u32 l = ROOT + 1;
-                    while (l < ROOT + sb && (w >> (ROOT + sb - l)) >= L.first[l] + L.cnt[l]) l++;
-                    const u32 sym = L.sorted[L.offs[l] + (w >> (ROOT + sb - l)) - L.first[l]];
+                    while (l < ROOT + sb && (w >> (ROOT + sb - l)) >= L.h.first[l] + L.h.cnt[l]) l++;
+                    const u32 sym = L.h.sorted[L.h.offs[l] + (w >> (ROOT + sb - l)) - L.h.first[l]];
                     tab[my_off + (__brev(v) >> (32 - sb))] = sym_entry(TYPE, sym, l);
                 }
             }
@@ -403,15 +425,40 @@ struct Out {
     u32 pos;            // bytes produced
 };
 
-// readRawData (flate/reader.go:137-159): n bytes from stream position sp to the output.
+// readRawData (flate/reader.go:137-159): n bytes from stream position sp to the output,
+// 16 bytes per lane and step with the stores aligned (the loads may straddle).
 __device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32 n, u32 lane) {
-    const u8 *src = r.comp + r.base_al + r.lead;
-    for (u32 k = lane; k < n; k += 64) {
-        const u32 idx = sp + k;
-        u8 b;
-        if (idx < r.csize) b = src[idx];
-        else { const u32 t = idx - r.csize; b = (t == 0) ? 0x01 : (t >= 3 ? 0xff : 0x00); }
-        o.raw[o.pos + k] = b;
+    const u8 *src = r.comp + r.base_al + r.lead + sp;
+    u8 *dst = o.raw + o.pos;
+    u32 fast = 0;                                               // bytes inside the chunk proper
+    if (sp < r.csize) fast = n < r.csize - sp ? n : r.csize - sp;
+    u32 head = (u32)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (head > fast) head = fast;
+    if (lane < head) dst[lane] = src[lane];
+    const u32 body = (fast - head) >> 4;
+    u32 i = lane;
+    for (; i + 192 < body; i += 256) {                          // four loads in flight per lane
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, src + head + (size_t)i * 16, 16);
+        __builtin_memcpy(&v1, src + head + (size_t)(i + 64) * 16, 16);
+        __builtin_memcpy(&v2, src + head + (size_t)(i + 128) * 16, 16);
+        __builtin_memcpy(&v3, src + head + (size_t)(i + 192) * 16, 16);
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)i * 16) = v0;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 64) * 16) = v1;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 128) * 16) = v2;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 192) * 16) = v3;
+    }
+    for (; i < body; i += 64) {
+        uint4 v;
+        __builtin_memcpy(&v, src + head + (size_t)i * 16, 16);
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)i * 16) = v;
+    }
+    const u32 done = head + body * 16;
+    if (done + lane < fast) dst[done + lane] = src[done + lane];
+    // a stored block that claims more than the chunk holds runs into the appended endBlock
+    for (u32 k = fast + lane; k < n; k += 64) {
+        const u32 t = sp + k - r.csize;
+        dst[k] = (t == 0) ? 0x01 : (t >= 3 ? 0xff : 0x00);
     }
     o.pos += n;
 }
@@ -429,7 +476,7 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
     if (hlit > 286 || hdist > 30) return XFG_ST_CORRUPTED;      // prefix.go:87-89
 
     // code-length code lengths, 3 bits each, in clenLens order (prefix.go:67,92-98)
-    if (lane < 19) L.clens[lane] = 0;
+    if (lane < 19) L.h.clens[lane] = 0;
     wave_sync();
     for (u32 i = 0; i < hclen; i++) {
         if (r.bitcnt < 3) refill(r);
@@ -442,10 +489,10 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
         else if (i == 3) s = 0;
         else if ((i & 1) == 0) s = 8 + ((i - 4) >> 1);          // i=4,6,8,..,18 -> 8,9,10,..,15
         else s = 7 - ((i - 5) >> 1);                            // i=5,7,9,..,17 -> 7,6,5,..,1
-        if (lane == 0) L.clens[s] = (u8)v;
+        if (lane == 0) L.h.clens[s] = (u8)v;
     }
     wave_sync();
-    const int cst = build_table<T_CLEN, CLEN_ROOT>(L, L.clen, L.clens, 19, lane);
+    const int cst = build_table<T_CLEN, CLEN_ROOT, 0>(L, L.h.clen, L.h.clens, 19, lane);
     if (cst == 2) return XFG_ST_CORRUPTED;
 
     // literal/length and distance code lengths with the 16/17/18 repeaters (prefix.go:125-165)
@@ -454,13 +501,13 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
     for (u32 sym = 0; sym < max_syms;) {
         if (cst == 1) return XFG_ST_CORRUPTED;                  // "decode with empty prefix tree"
         if (r.bitcnt < 32) refill(r);
-        const u32 e = lookup<CLEN_ROOT>(L.clen, r.bitbuf);
+        const u32 e = lookup<CLEN_ROOT>(L.h.clen, r.bitbuf);
         if ((i32)e_nbits(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
         consume(r, e_nbits(e));
         if (e_kind(e) == K_INVALID) return XFG_ST_CORRUPTED;    // the degenerate filler symbol
         const u32 c = e_val(e);
         if (c < 16) {
-            if (lane == 0) L.lens[sym] = (u8)c;
+            if (lane == 0) L.h.lens[sym] = (u8)c;
             prev = c;
             sym++;
             continue;
@@ -476,15 +523,15 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
         consume(r, nb);
         if (c != 16 && rfc_rep16) prev = 0;                     // stdlib: 16 repeats the previous array entry
         const u32 end = sym + rep;
-        for (u32 k = sym + lane; k < end && k < max_syms; k += 64) L.lens[k] = (u8)val;
+        for (u32 k = sym + lane; k < end && k < max_syms; k += 64) L.h.lens[k] = (u8)val;
         sym = end;
         if (sym > max_syms) return XFG_ST_CORRUPTED;            // prefix.go:161-163
     }
     wave_sync();
     // lens[0 .. hlit) literal/length, lens[hlit .. hlit+hdist) distance
-    lit_state = build_table<T_LIT, LIT_ROOT>(L, L.lit, L.lens, hlit, lane);
+    lit_state = build_table<T_LIT, LIT_ROOT, 0>(L, L.tab, L.h.lens, hlit, lane);
     if (lit_state == 2) return XFG_ST_CORRUPTED;
-    dist_state = build_table<T_DIST, DIST_ROOT>(L, L.dist, L.lens + hlit, hdist, lane);
+    dist_state = build_table<T_DIST, DIST_ROOT, LIT_TAB>(L, (L.tab + LIT_TAB), L.h.lens + hlit, hdist, lane);
     if (dist_state == 2) return XFG_ST_CORRUPTED;
     return XFG_ST_OK;
 }
@@ -492,19 +539,19 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
 // Fixed code sets of RFC 1951 3.2.6 (flate/prefix.go:35-63).
 __device__ void build_fixed(WaveLds &L, u32 lane) {
     for (u32 i = lane; i < 288; i += 64)
-        L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+        L.h.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
     wave_sync();
-    build_table<T_LIT, LIT_ROOT>(L, L.lit, L.lens, 288, lane);
-    if (lane < 32) L.clens[lane] = 5;
+    build_table<T_LIT, LIT_ROOT, 0>(L, L.tab, L.h.lens, 288, lane);
+    if (lane < 32) L.h.clens[lane] = 5;
     wave_sync();
-    build_table<T_DIST, DIST_ROOT>(L, L.dist, L.clens, 32, lane);
+    build_table<T_DIST, DIST_ROOT, LIT_TAB>(L, (L.tab + LIT_TAB), L.h.clens, 32, lane);
 }
 
 // ---------------------------------------------------------------------------
 // Lane-parallel decode of one Huffman block: readBlock (flate/reader.go:162-250)
 // and dictDecoder (flate/dict_decoder.go:86-132) for 64 segments at a time.
 // ---------------------------------------------------------------------------
-enum : u32 { F_NONE = 0, F_EOB = 1, F_CORRUPT = 2, F_EOF = 3, F_DIST = 4, F_PANIC = 5 };
+enum : u32 { F_NONE = 0, F_EOB = 1, F_CORRUPT = 2, F_EOF = 3, F_DIST = 4 };
 
 struct Seg {
     u32 end;        // bit position after the last token decoded
@@ -518,115 +565,163 @@ __device__ __forceinline__ u64 lds_load64(const u8 *p) {
     __builtin_memcpy(&v, p, 8);                                 // ds_read_b64, any byte alignment
     return v;
 }
+__device__ __forceinline__ u32 lds_load32(const u8 *p) {
+    u32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ void lds_store64(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ void lds_store32(u8 *p, u32 v) { __builtin_memcpy(p, &v, 4); }
 
-// Load the compressed bytes [wb0, wb0 + BWIN_BYTES) of the virtual stream into L.win.
-// wb0 (may be negative by < 16) is chosen so that the global address is 16-byte aligned.
-__device__ void load_batch_window(const Reader &r, WaveLds &L, i32 wb0, u32 lane) {
+// The compressed bytes [wb0, wb0 + BWIN_BYTES) of the virtual stream, 16 bytes per lane and
+// unit, into registers.  wb0 (may be negative by < 16) is chosen so that the global address
+// is 16-byte aligned.  Bytes past the stream read as the endBlock, then zero.
+__device__ __forceinline__ void fetch_batch_window(const Reader &r, i32 wb0, u32 lane, uint4 (&pf)[NPF]) {
     const u8 *src = r.comp + r.base_al + r.lead;                // stream byte 0
-    u8 *dst = reinterpret_cast<u8 *>(L.win);
-    for (u32 o = lane * 16; o < (u32)BWIN_BYTES; o += 64 * 16) {
+#pragma unroll
+    for (int u = 0; u < NPF; u++) {
+        const u32 o = (u32)u * 1024u + lane * 16u;
         const i32 ci = wb0 + (i32)o;
-        uint4 v;
-        if (ci >= 0 && ci + 16 <= (i32)r.csize) {
-            v = *reinterpret_cast<const uint4 *>(src + ci);
-        } else {
-            u32 w[4] = {0, 0, 0, 0};
-            for (int j = 0; j < 16; j++) {
-                const i32 idx = ci + j;
-                u32 bb = 0;
-                if (idx >= 0) {
-                    if (idx < (i32)r.csize) bb = src[idx];
-                    else if (idx < (i32)r.total) {
-                        const u32 t = (u32)idx - r.csize;       // 01 00 00 ff ff
-                        bb = (t == 0) ? 0x01u : (t >= 3 ? 0xffu : 0x00u);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (o < (u32)BWIN_BYTES) {
+            if (ci >= 0 && ci + 16 <= (i32)r.csize) {
+                v = *reinterpret_cast<const uint4 *>(src + ci);
+            } else if (ci + 16 > 0 && ci < (i32)r.total) {
+                u32 w[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 16; j++) {
+                    const i32 idx = ci + j;
+                    u32 bb = 0;
+                    if (idx >= 0) {
+                        if (idx < (i32)r.csize) bb = src[idx];
+                        else if (idx < (i32)r.total) {
+                            const u32 t = (u32)idx - r.csize;   // 01 00 00 ff ff (xflate/common.go:57)
+                            bb = (t == 0) ? 0x01u : (t >= 3 ? 0xffu : 0x00u);
+                        }
                     }
+                    w[j >> 2] |= bb << (8 * (j & 3));
                 }
-                w[j >> 2] |= bb << (8 * (j & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        *reinterpret_cast<uint4 *>(dst + o) = v;
+        pf[u] = v;
+    }
+}
+__device__ __forceinline__ void store_batch_window(WaveLds &L, u32 lane, const uint4 (&pf)[NPF]) {
+    u8 *dst = reinterpret_cast<u8 *>(L.win);
+#pragma unroll
+    for (int u = 0; u < NPF; u++) {
+        const u32 o = (u32)u * 1024u + lane * 16u;
+        if (o < (u32)BWIN_BYTES) *reinterpret_cast<uint4 *>(dst + o) = pf[u];
     }
 }
 
-// Decode the tokens that START in [start, seg_end) (or until T_MAX matches).
-// EMIT = false: count only.  EMIT = true: literals go to the LDS output window at orel..
-// (obase = the same position counted from the start of the chunk), matches to mlist.
-template <bool EMIT>
-__device__ __forceinline__ Seg decode_segment(const WaveLds &L, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
-                                              bool dist_empty, u8 *outw, u32 orel, u32 obase, u32 *mlist, u32 lane,
-                                              u32 &err_out)
+// Decode the tokens that START in [start, seg_end), or until the lane's output cap.
+// One table lookup per iteration: a lane is at a literal/length root entry, at a distance
+// root entry or at a second-level entry; which one is per-lane state (tbase/tshift/twidth,
+// in_dist), so lanes in different states still share the instruction stream.
+// The bit buffer holds >= 56 valid bits at every lookup; one step consumes <= 28.
+//   EMIT = false: count only.  EMIT = true: literals go to the LDS output window at orel..
+//   (obase = the same position counted from the start of the chunk), matches to tok/tdst at moff..
+//   TAIL = true: the batch may run past the end of the stream; every read of the reference
+//   that can fail with io.ErrUnexpectedEOF is checked at the same point.
+template <bool EMIT, bool TAIL>
+__device__ __forceinline__ Seg decode_segment(WaveLds &L, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
+                                              bool dist_empty, u32 orel, u32 obase, u32 moff, u32 &err_out)
 {
     const u8 *win = reinterpret_cast<const u8 *>(L.win);
-    u32 pos = start, nout = 0, nm = 0, flag = F_NONE, gap = 0;
-    u32 guard = 0;
-    while (pos < seg_end) {
-        if (++guard > 64u * SEG_BITS + 64) { flag = F_PANIC; break; }  // every token consumes >= 1 bit
-        const u64 bits = lds_load64(win + ((i32)(pos >> 3) - wb0)) >> (pos & 7);    // >= 57 valid bits
-        u32 e = L.lit[(u32)bits & ((1u << LIT_ROOT) - 1)];
-        if (e_kind(e) == K_SUB)
-            e = L.lit[e_val(e) + (((u32)(bits >> LIT_ROOT)) & ((1u << e_extra(e)) - 1))];
-        u32 n = e_nbits(e);
-        if (pos + n > total_bits) { flag = F_EOF; break; }
+    u8 *outw = reinterpret_cast<u8 *>(L.out);
+    u32 wp = (u32)((i32)(start >> 3) - wb0);
+    u64 buf = lds_load64(win + wp) >> (start & 7);
+    u32 cnt = 56 - (start & 7);                                 // account 7 of the 8 bytes: cnt stays below 64
+    wp += 7;
+    u64 nextw = lds_load64(win + wp);
+    u32 pos = start, nout = 0, nm = 0, flag = F_NONE;
+    u32 tbase = 0, tshift = 0, twidth = LIT_ROOT;
+    u32 len = 0;
+    bool in_dist = false;
+    for (;;) {
+        // top up to >= 56 bits; the following 8 bytes are already on their way for the next top-up
+        buf |= nextw << cnt;
+        wp += (63 - cnt) >> 3;
+        cnt |= 56;
+        nextw = lds_load64(win + wp);
+        const u32 lo = (u32)buf;
+        const u32 e = L.tab[tbase + ((lo >> tshift) & ((1u << twidth) - 1))];
         const u32 kind = e_kind(e);
-        if (kind == K_LIT) {
-            if (EMIT) outw[orel + nout] = (u8)e_val(e);
-            nout++; gap++;
-            pos += n;
+        if (kind == K_SUB) {                                    // second-level table: look again, nothing consumed
+            tbase = e_val(e);
+            twidth = e_extra(e);
+            tshift = in_dist ? (u32)DIST_ROOT : (u32)LIT_ROOT;
             continue;
         }
-        pos += n;
-        if (kind == K_EOB) { flag = F_EOB; break; }
-        if (kind != K_BASE) { flag = F_CORRUPT; break; }        // 286/287 or the degenerate filler
-        const u32 xb = e_extra(e);
-        if (pos + xb > total_bits) { flag = F_EOF; break; }
-        const u32 len = e_val(e) + (((u32)(bits >> n)) & ((1u << xb) - 1));
-        pos += xb; n += xb;
-        if (dist_empty) { flag = F_CORRUPT; break; }            // decode with empty prefix tree
-        const u32 db = (u32)(bits >> n);
-        u32 d = L.dist[db & ((1u << DIST_ROOT) - 1)];
-        if (e_kind(d) == K_SUB)
-            d = L.dist[e_val(d) + ((db >> DIST_ROOT) & ((1u << e_extra(d)) - 1))];
-        const u32 dn = e_nbits(d);
-        if (pos + dn > total_bits) { flag = F_EOF; break; }
-        pos += dn; n += dn;
-        if (e_kind(d) != K_BASE) { flag = F_CORRUPT; break; }   // distance symbols 30/31 or the filler
-        const u32 dxb = e_extra(d);
-        if (pos + dxb > total_bits) { flag = F_EOF; break; }
-        const u32 dist = e_val(d) + (((u32)(bits >> n)) & ((1u << dxb) - 1));
-        pos += dxb;
-        if (EMIT) {
-            const u32 dst = obase + nout;
-            const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;       // dictDecoder.HistSize
-            if (dist > hist) { flag = F_DIST; err_out = nout; break; }         // flate/reader.go:223-225
-            mlist[nm * 64 + lane] = (len - 3) | ((dist - 1) << 8) | (gap << 23);
+        tshift = 0;
+        u32 n = e_nbits(e);
+        if (TAIL && pos + n > total_bits) { flag = F_EOF; break; }
+        bool done;                                              // a token boundary has been reached
+        if (!in_dist) {
+            if (kind == K_LIT) {
+                if (EMIT) outw[orel + nout] = (u8)e_val(e);
+                nout++;
+                tbase = 0; twidth = LIT_ROOT;
+                done = true;
+            } else if (kind == K_BASE) {
+                const u32 xb = e_extra(e);
+                if (TAIL && pos + n + xb > total_bits) { pos += n; flag = F_EOF; break; }
+                len = e_val(e) + ((lo >> n) & ((1u << xb) - 1));
+                n += xb;
+                if (dist_empty) { pos += n; flag = F_CORRUPT; break; }  // decode with empty prefix tree
+                in_dist = true;
+                tbase = LIT_TAB; twidth = DIST_ROOT;
+                done = false;
+            } else {
+                pos += n;
+                flag = (kind == K_EOB) ? F_EOB : F_CORRUPT;     // 286/287 or the degenerate filler
+                break;
+            }
+        } else {
+            if (kind != K_BASE) { pos += n; flag = F_CORRUPT; break; }   // distance symbols 30/31 or the filler
+            const u32 dxb = e_extra(e);
+            if (TAIL && pos + n + dxb > total_bits) { pos += n; flag = F_EOF; break; }
+            const u32 dist = e_val(e) + ((lo >> n) & ((1u << dxb) - 1));
+            n += dxb;
+            if (EMIT) {
+                const u32 dst = obase + nout;
+                const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;       // dictDecoder.HistSize
+                if (dist > hist) { pos += n; flag = F_DIST; err_out = nout; break; }   // flate/reader.go:223-225
+                L.tok[moff + nm] = (len - 3) | ((dist - 1) << 8);
+                L.tdst[moff + nm] = (u16)(orel + nout);
+            }
+            nout += len; nm++;
+            in_dist = false;
+            tbase = 0; twidth = LIT_ROOT;
+            done = true;
+            if (nout >= (u32)OUT_CAP) { buf >>= n; cnt -= n; pos += n; break; }  // behaves like a segment end
         }
-        nout += len; nm++; gap = 0;
-        if (nm == (u32)T_MAX) break;                            // behaves like a segment end
+        buf >>= n; cnt -= n; pos += n;
+        if (done && pos >= seg_end) break;
     }
     Seg r;
     r.end = pos; r.nout = nout; r.nmatch = nm; r.flag = flag;
     return r;
 }
 
-__device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 lane, u32 &total) {
-    u32 incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 t = __shfl_up(incl, d);
-        if (lane >= (u32)d) incl += t;
-    }
-    total = uni(__shfl(incl, 63));
+// Inclusive prefix sum over the wave with DPP row shifts and row broadcasts (no LDS traffic).
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 &total) {
+    const u32 incl = wave_incl_scan(v);
+    total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
     return incl - v;
 }
-
-__device__ __forceinline__ u32 wave_max(u32 v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const u32 t = __shfl_xor(v, d);
-        v = t > v ? t : v;
-    }
-    return uni(v);
+__device__ __forceinline__ u32 lane_get(u32 v, u32 l) {       // l is wave-uniform
+    return (u32)__builtin_amdgcn_readlane((int)v, (int)l);
 }
 
 __device__ __forceinline__ void mem_sync() {
@@ -636,105 +731,106 @@ __device__ __forceinline__ void mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// n bytes global -> LDS, any alignment.
-__device__ __forceinline__ void copy_g2l(u8 *dst, const u8 *src, u32 n) {
-    u32 j = 0;
-    for (; j + 16 <= n; j += 16) {
-        u64 a, b2;
-        __builtin_memcpy(&a, src + j, 8);
-        __builtin_memcpy(&b2, src + j + 8, 8);
-        __builtin_memcpy(dst + j, &a, 8);
-        __builtin_memcpy(dst + j + 8, &b2, 8);
+// n <= 16 bytes LDS -> LDS, any alignment, ranges disjoint: both reads happen before both writes.
+__device__ __forceinline__ void copy16_l2l(u8 *dst, const u8 *src, u32 n) {
+    if (n >= 8) {
+        const u64 a = lds_load64(src), b = lds_load64(src + n - 8);
+        lds_store64(dst, a);
+        lds_store64(dst + n - 8, b);
+    } else if (n >= 4) {
+        const u32 a = lds_load32(src), b = lds_load32(src + n - 4);
+        lds_store32(dst, a);
+        lds_store32(dst + n - 4, b);
+    } else {                                                    // 1..3
+        const u32 m = n > 1 ? 1u : 0u;
+        const u8 a = src[0], b = src[m], c = src[n - 1];
+        dst[0] = a; dst[m] = b; dst[n - 1] = c;
     }
-    if (j + 8 <= n) {
-        u64 a;
-        __builtin_memcpy(&a, src + j, 8);
-        __builtin_memcpy(dst + j, &a, 8);
-        j += 8;
-    }
-    for (; j < n; j++) dst[j] = src[j];
 }
-// n bytes LDS -> LDS, ranges disjoint, any alignment.
-__device__ __forceinline__ void copy_l2l(u8 *dst, const u8 *src, u32 n) {
-    u32 j = 0;
-    for (; j + 8 <= n; j += 8) {
-        u64 a;
-        __builtin_memcpy(&a, src + j, 8);
-        __builtin_memcpy(dst + j, &a, 8);
+// n <= 16 bytes global -> LDS, any alignment.
+__device__ __forceinline__ void copy16_g2l(u8 *dst, const u8 *src, u32 n) {
+    if (n >= 8) {
+        u64 a, b;
+        __builtin_memcpy(&a, src, 8);
+        __builtin_memcpy(&b, src + n - 8, 8);
+        lds_store64(dst, a);
+        lds_store64(dst + n - 8, b);
+    } else if (n >= 4) {
+        u32 a, b;
+        __builtin_memcpy(&a, src, 4);
+        __builtin_memcpy(&b, src + n - 4, 4);
+        lds_store32(dst, a);
+        lds_store32(dst + n - 4, b);
+    } else {
+        const u32 m = n > 1 ? 1u : 0u;
+        const u8 a = src[0], b = src[m], c = src[n - 1];
+        dst[0] = a; dst[m] = b; dst[n - 1] = c;
     }
-    for (; j < n; j++) dst[j] = src[j];
 }
 
-// Stage 2: resolve the match tokens of one batch inside the LDS output window.
+// Stage 2: resolve the M match tokens of one batch inside the LDS output window, round-major.
 //   raw/base   the chunk's output so far: bytes [0, base) are final in HBM
 //   outw       the batch's bytes [base, base + total) live at outw[0, total); literals are in place
-//   my_rel     where this lane's tokens start in outw
-// Pass A copies every match whose source lies entirely before `base` (HBM -> LDS, no
-// dependencies).  Pass B runs rounds over the rest: a match is ready when its source is
-// below the watermark (the destination of the earliest unresolved match) or inside the
-// lane's own finished part; overlapping matches double their period each round.
-__device__ void resolve_matches(const u8 *raw, u32 base, u8 *outw, const u32 *mlist, u32 nm, u32 my_rel, u32 lane) {
-    // ---- pass A: sources before the batch
-    const u32 max_nm = wave_max(nm);
-    {
-        u32 cur = my_rel;
-        for (u32 k = 0; k < max_nm; k++) {
-            if (k < nm) {
-                const u32 m = mlist[k * 64 + lane];
-                const u32 len = (m & 255) + 3, dist = ((m >> 8) & 32767) + 1, gap = m >> 23;
-                const u32 dst = cur + gap;
-                if (dist >= dst + len)                          // src + len <= base  <=>  dist - dst >= len
-                    copy_g2l(outw + dst, raw + (base + dst - dist), len);
-                cur = dst + len;
-            }
-        }
-    }
-    wave_sync();
-    // ---- pass B: sources inside the batch (or straddling its start)
-    u32 k = 0, cur = my_rel;
-    u32 dst = 0, dist = 0, rem = 0, span = 0;
-    bool loaded = false;
-    u32 round = 0;
-    for (; round < 64u * T_MAX * 12u; round++) {                // each round retires >= 1 copy step
-        while (k < nm && !loaded) {
-            const u32 m = mlist[k * 64 + lane];
-            const u32 len = (m & 255) + 3, gap = m >> 23;
-            dist = ((m >> 8) & 32767) + 1;
-            dst = cur + gap;
-            if (dist >= dst + len) { cur = dst + len; k++; continue; }     // done in pass A
-            rem = len;
-            span = dist;
-            loaded = true;
-        }
-        const bool have = k < nm;
-        const u64 pending = __ballot(have);
-        if (pending == 0) break;
-        const u32 first = (u32)__ffsll((long long)pending) - 1;
-        const u32 water = uni(__shfl(dst, first));               // everything below is final
+// Round r takes tokens [64r, 64r + 64) of the stream, one per lane.  Source bytes before the
+// window come from HBM/L2 and depend on nothing in the batch.  Source bytes inside the window
+// are final once they lie below the destination of the first unresolved token of the round
+// (all earlier rounds are complete, and every literal is in place), so every pass of the
+// inner loop retires at least that token.  A started copy never waits again: what it reads
+// beyond its foreign source bytes it has written itself.
+__device__ void resolve_tokens(const u8 *raw, u32 base, WaveLds &L, u32 M, u32 lane) {
+    u8 *outw = reinterpret_cast<u8 *>(L.out);
+    u32 rounds = 0;
+    for (u32 r0 = 0; r0 < M; r0 += 64) {
+        const u32 m = r0 + lane;
+        const bool have = m < M;
+        u32 d = 0, len = 0, dist = 1;
         if (have) {
-            if (dist > dst) {
-                // The source starts before the batch: bytes [base+dst-dist, base) come from HBM.
-                u32 n = dist - dst;
-                if (n > rem) n = rem;
-                copy_g2l(outw + dst, raw + (base + dst - dist), n);
-                dst += n; rem -= n;
-            } else {
-                // out[dst + j] = out[dst + j - span]: span is a multiple of dist that doubles every time a
-                // whole span has been copied, so an overlapping match needs log2(len / dist) rounds.
-                const u32 src = dst - span;
-                const u32 n = span < rem ? span : rem;
-                const bool ready = (src + n <= water) || (src >= my_rel);
-                if (ready) {
-                    copy_l2l(outw + dst, outw + src, n);
-                    dst += n; rem -= n;
-                    if (n == span) span *= 2;
-                }
+            const u32 t = L.tok[m];
+            d = L.tdst[m];
+            len = (t & 255) + 3;
+            dist = (t >> 8) + 1;
+        }
+        u32 cur = d, rem = len;
+        const i32 s = (i32)d - (i32)dist;                       // source start, window-relative
+        // ---- bytes before the window
+        if (s < 0) {
+            u32 g = (u32)(-s);
+            if (g > rem) g = rem;
+            const u8 *src = raw + base - (u32)(-s);             // >= raw: dist <= history was checked by the emitter
+            u32 off = 0;
+            while (off < g) {
+                const u32 n = g - off < 16 ? g - off : 16;
+                copy16_g2l(outw + cur + off, src + off, n);
+                off += n;
             }
-            if (rem == 0) { cur = dst; k++; loaded = false; }
+            cur += g; rem -= g;
+        }
+        // ---- bytes inside the window
+        const i32 e = s + (i32)(len < dist ? len : dist);       // end of the source bytes other tokens may own
+        bool pending = rem > 0;
+        u32 span = dist;
+        for (;;) {
+            const u64 pm = __ballot(pending);
+            if (pm == 0) break;
+            rounds++;
+            const u32 first = (u32)__ffsll((long long)pm) - 1;
+            const i32 water = (i32)lane_get(d, first);          // everything below is final
+            if (pending && e <= water) {
+                while (rem) {
+                    u32 n = span < rem ? span : rem;
+                    if (n > 16) n = 16;
+                    copy16_l2l(outw + cur, outw + cur - span, n);
+                    cur += n; rem -= n;
+                    if (n == span) span *= 2;                   // [cur - 2 span, cur) now has period dist
+                }
+                pending = false;
+            }
+            wave_sync();
         }
         wave_sync();
     }
-    PROF_CNT(PF_N_ROUNDS, round, lane);
+    PROF_CNT(PF_N_ROUNDS, rounds, lane);
+    (void)rounds;
 }
 
 // Flush outw[0, n) to raw[base, base + n), coalesced 16-byte stores where the HBM address allows.
@@ -760,26 +856,31 @@ struct BlockEnd {
 
 // Decode one Huffman block that starts at bit position p0.  Output goes to o.raw at o.pos.
 __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u32 lane, u32 p0,
-                                         int lit_state, int dist_state, u32 *mlist)
+                                         int lit_state, int dist_state)
 {
     BlockEnd be;
     if (lit_state == 1) { be.status = XFG_ST_CORRUPTED; be.bitpos = p0; return be; }   // empty literal tree
     const u32 total_bits = r.total * 8;
     const bool dist_empty = dist_state == 1;
+    const i64 stream0 = (i64)(r.base_al + r.lead);              // address of stream byte 0, relative to comp
+    uint4 pf[NPF];
+    bool have_pf = false;
     for (u32 nbatch = 0;; nbatch++) {
         if (nbatch > total_bits + 4) { be.status = XFG_ST_INTERNAL; be.bitpos = p0; return be; }   // every batch consumes >= 1 bit
-        // ---- compressed window of this batch
-        const i64 abs0 = (i64)(r.base_al + r.lead) + (p0 >> 3);
-        const i32 wb0 = (i32)((abs0 & ~(i64)15) - (i64)(r.base_al + r.lead));
+        // ---- compressed window of this batch (fetched during the previous batch's stage 2 when there was one)
+        const i32 wb0 = (i32)(((stream0 + (p0 >> 3)) & ~(i64)15) - stream0);
         {
             PROF_T0();
+            if (!have_pf) fetch_batch_window(r, wb0, lane, pf);
             wave_sync();
-            load_batch_window(r, L, wb0, lane);
+            store_batch_window(L, lane, pf);
             wave_sync();
             PROF_ADD(PF_WINDOW, lane);
         }
+        have_pf = false;
         PROF_CNT(PF_N_BATCH, 1, lane);
         PROF_T0();
+        const bool tail = p0 + 64u * SEG_BITS + 64u > total_bits;      // wave-uniform
 
         // ---- stage 1a: speculative passes until the chain of segment starts is stable
         u32 start = p0 + lane * SEG_BITS;
@@ -790,15 +891,17 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         u32 dummy = 0;
         u32 verified = 64;
         for (int pass = 1;; pass++) {
-            if (dirty && !dead)
-                sg = decode_segment<false>(L, wb0, start, seg_end, total_bits, dist_empty, nullptr, 0, 0, nullptr, lane, dummy);
+            if (dirty && !dead) {
+                if (tail) sg = decode_segment<false, true>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
+                else      sg = decode_segment<false, false>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
+            }
             PROF_CNT(PF_N_PASS, 1, lane);
             const u32 pe = __shfl_up(sg.end, 1);
-            const u32 pf = __shfl_up(sg.flag, 1);
+            const u32 pfl = __shfl_up(sg.flag, 1);
             const u32 pd = __shfl_up((u32)dead, 1);
             u32 ns = p0;
             bool nd = false;
-            if (lane > 0) { nd = pd != 0 || pf != F_NONE; ns = pe; }
+            if (lane > 0) { nd = pd != 0 || pfl != F_NONE; ns = pe; }
             dirty = (nd != dead) || (!nd && ns != start);
             start = ns; dead = nd;
             if (dead) { sg.end = 0; sg.nout = 0; sg.nmatch = 0; sg.flag = F_NONE; }
@@ -808,69 +911,75 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             if ((pass >= 2 && fd >= 40) || pass >= MAX_PASSES) { verified = fd; break; }
         }
         PROF_ADD(PF_COUNT, lane);
-        const bool live = !dead && lane < verified;
-        const u64 lm = __ballot(live);
-        const u32 nlive = (u32)__popcll(lm);                      // live lanes are 0 .. nlive-1
+        const bool live = !dead && lane < verified;              // live lanes are 0 .. nlive-1
 
-        // ---- output offsets; keep the prefix of lanes whose output fits the LDS window
-        u32 total_out;
-        u32 rel = wave_excl_scan(live ? sg.nout : 0, lane, total_out);
-        bool keep = live && (rel + sg.nout <= (u32)OUT_LDS);
-        const u64 km = __ballot(keep);
-        // kept lanes must be a prefix: cut at the first live lane that does not fit
-        const u64 cut = lm & ~km;
-        u32 nkeep = nlive;
-        if (cut) nkeep = (u32)__ffsll((long long)cut) - 1;       // >= 1: one lane's output always fits
-        keep = lane < nkeep;
-        rel = wave_excl_scan(keep ? sg.nout : 0, lane, total_out);
+        // ---- output and token offsets; keep the prefix of lanes that fits the output window and the token list
+        u32 tot_o, tot_m;
+        const u32 rel = wave_excl_scan(live ? sg.nout : 0, tot_o);
+        const u32 moff = wave_excl_scan(live ? sg.nmatch : 0, tot_m);
+        const bool keep = live && rel + sg.nout <= (u32)OUT_LDS && moff + sg.nmatch <= (u32)TOK_MAX;
+        const u32 nkeep = (u32)__popcll(__ballot(keep));        // >= 1: lane 0 is live and one lane always fits
         const u32 lastl = nkeep - 1;
+        u32 total_out = lane_get(rel + sg.nout, lastl);
+        u32 M = lane_get(moff + sg.nmatch, lastl);
+        const u32 lflag = lane_get(sg.flag, lastl);
+        const u32 lend = lane_get(sg.end, lastl);
         PROF_CNT(PF_N_LIVE, nkeep, lane);
-        u8 *outw = reinterpret_cast<u8 *>(L.out);
+
+        // ---- the next batch's compressed window: on its way while this batch is emitted and resolved
+        if (lflag == F_NONE && lend > p0) {
+            const i32 nwb0 = (i32)(((stream0 + (lend >> 3)) & ~(i64)15) - stream0);
+            fetch_batch_window(r, nwb0, lane, pf);
+            have_pf = true;
+        }
 
         // ---- stage 1b: final pass, literals into the output window, matches to the token list
         u32 err_out = 0;
         Seg fin = sg;
         {
             PROF_T0();
-            if (keep)
-                fin = decode_segment<true>(L, wb0, start, seg_end, total_bits, dist_empty, outw, rel, o.pos + rel, mlist, lane, err_out);
-            mem_sync();                                         // token list: written and read back by the same lane
+            if (keep) {
+                if (tail) fin = decode_segment<true, true>(L, wb0, start, seg_end, total_bits, dist_empty, rel, o.pos + rel, moff, err_out);
+                else      fin = decode_segment<true, false>(L, wb0, start, seg_end, total_bits, dist_empty, rel, o.pos + rel, moff, err_out);
+            }
+            wave_sync();
             PROF_ADD(PF_EMIT, lane);
         }
 
         // A distance beyond the history ends the chunk at that token (flate/reader.go:223-225).
         const u64 em = __ballot(keep && fin.flag == F_DIST);
-        u32 nm = keep ? fin.nmatch : 0;
         u32 elane = 64;
         if (em) {
             elane = (u32)__ffsll((long long)em) - 1;
-            if (lane > elane) nm = 0;                            // tokens after the error do not exist
-            total_out = uni(__shfl(rel + err_out, elane));
+            total_out = lane_get(rel + err_out, elane);         // tokens after the error do not exist
+            M = lane_get(moff + fin.nmatch, elane);
         }
+        PROF_CNT(PF_N_TOKENS, M, lane);
         // ---- stage 2
-        {
+        if (M) {
             PROF_T0();
-            resolve_matches(o.raw, o.pos, outw, mlist, nm, rel, lane);
+            mem_sync();                                         // earlier batches' flushed bytes are read back here
+            resolve_tokens(o.raw, o.pos, L, M, lane);
             PROF_ADD(PF_RESOLVE, lane);
         }
         // ---- flush to HBM (never beyond the chunk's capacity)
         {
+            PROF_T0();
             u32 nflush = total_out;
             if (o.pos >= o.cap) nflush = 0; else if (nflush > o.cap - o.pos) nflush = o.cap - o.pos;
             wave_sync();
-            flush_output(o.raw, o.pos, outw, nflush, lane);
-            mem_sync();                                         // later batches read these bytes back
+            flush_output(o.raw, o.pos, reinterpret_cast<const u8 *>(L.out), nflush, lane);
+            wave_sync();
+            PROF_ADD(PF_FLUSH, lane);
         }
 
         if (em) {
             be.status = XFG_ST_CORRUPTED;
-            be.bitpos = uni(__shfl(fin.end, elane));
+            be.bitpos = lane_get(fin.end, elane);
             o.pos += total_out;
             if (o.pos > o.cap) { o.pos = o.cap; be.status = XFG_ST_OUT_FULL; }
             return be;
         }
-        const u32 lflag = uni(__shfl(sg.flag, lastl));
-        const u32 lend = uni(__shfl(sg.end, lastl));
         if (total_out > o.cap - o.pos) {                         // more output than the chunk may hold
             o.pos = o.cap;
             be.status = XFG_ST_OUT_FULL;
@@ -889,7 +998,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
 // Inflate one chunk; returns through *out.  Everything here is wave-uniform control flow.
 __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 ci,
                               u8 *__restrict__ raw, xfg_result *__restrict__ res,
-                              WaveLds &L, u32 lane, u32 *mlist)
+                              WaveLds &L, u32 lane)
 {
     PROF_T0();
     xfg_chunk c = chunks[ci];
@@ -971,7 +1080,7 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
                 if (status != XFG_ST_OK) break;
             }
             PROF_CNT(PF_N_BLOCKS, 1, lane);
-            const BlockEnd be = decode_huffman_block(r, o, L, lane, reader_bitpos(r), lit_state, dist_state, mlist);
+            const BlockEnd be = decode_huffman_block(r, o, L, lane, reader_bitpos(r), lit_state, dist_state);
             wave_sync();
             reader_seek(r, be.bitpos);                          // the window was reused by the block decoder
             status = be.status;
@@ -1015,7 +1124,6 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
 }
 
 // Persistent grid: wave w of the grid takes chunks w, w + W, w + 2W, ...
-// scratch holds SCRATCH_WORDS_PER_WAVE u32 (match-token lists) per wave of the grid.
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
 inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
                       u8 *__restrict__ raw, xfg_result *__restrict__ res,
@@ -1025,11 +1133,11 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
     const u32 wave = uni(threadIdx.x >> 6);
     const u32 lane = threadIdx.x & 63;
     WaveLds &L = lds[wave];
-    u32 *mlist = scratch + (size_t)(blockIdx.x * WAVES_PER_BLOCK + wave) * SCRATCH_WORDS_PER_WAVE;
+    (void)scratch;
     // Static round-robin over the persistent grid: the trip count is provably wave-uniform.
     const u32 stride = gridDim.x * WAVES_PER_BLOCK;
     for (u32 ci = blockIdx.x * WAVES_PER_BLOCK + wave; ci < n; ci += stride)
-        inflate_chunk(comp, chunks, ci, raw, res, L, lane, mlist);
+        inflate_chunk(comp, chunks, ci, raw, res, L, lane);
 }
 
 } // namespace xfg
@@ -1070,7 +1178,8 @@ extern "C" uint32_t xfg_grid_blocks(uint32_t n, int num_cu)
 
 extern "C" size_t xfg_scratch_bytes(int num_cu)
 {
-    return (size_t)num_cu * xfg::MAX_BLOCKS_PER_CU * xfg::WAVES_PER_BLOCK * xfg::SCRATCH_WORDS_PER_WAVE * sizeof(uint32_t);
+    (void)num_cu;
+    return 256;                                                 // the token lists live in LDS; nothing is staged in HBM
 }
 
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,

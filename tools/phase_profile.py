@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from compress_amd import capi  # noqa: E402
 
 NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "total",
-         "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "n_iters", "n_tokens"]
+         "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens"]
 
 
 def main():
