@@ -78,27 +78,31 @@ constexpr int BATCH_BYTES = 64 * SEG_BITS / 8;
 constexpr int BWIN_BYTES = (BATCH_BYTES + 64) > 1024 ? (BATCH_BYTES + 64) : 1024;   // batch window: 16-byte alignment slack + over-read; >= the header ring
 constexpr int NPF = (BWIN_BYTES + 1023) / 1024;     // 16-byte units per lane that cover the batch window
 constexpr int OUT_LDS = XFG_OUT_LDS;    // bytes of batch output staged in LDS
-constexpr int OUT_CAP = OUT_LDS - SEG_BITS - 258;   // a lane stops after the match that takes it to OUT_CAP: one lane always fits
+constexpr int OUT_CAP = OUT_LDS - 258;  // a lane stops at the token that takes it to OUT_CAP: one lane always fits
 constexpr int TOK_MAX = XFG_TOK_MAX;    // match tokens per batch
 constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix
 static_assert(OUT_CAP >= 1024, "output window too small");
 static_assert(TOK_MAX >= SEG_BITS / 2, "one lane's tokens (>= 2 bits each) must fit the token list");
 static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
 
-// Table entry (u32):
-//   [4:0]   bits to consume for this code word (total code length, sub-table entries included)
-//   [7:5]   kind
-//   [12:8]  number of extra bits (length / distance) or sub-table index bits (K_SUB)
-//   [31:16] literal byte, length base, distance base, code-length symbol, or sub-table offset
-enum : u32 { K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SUB = 3, K_INVALID = 4 };
+// Table entry (u32): what one decode step does with the bits at the head of the buffer.
+//   [4:0]   bits to consume in this step: code word + extra bits (K_LEN / K_DIST), the code
+//           word (K_LIT / K_EOB / K_INVALID), or ROOT for a link to a second-level table (K_SUB);
+//           second-level entries hold what is left of the code word after ROOT bits
+//   [9:5]   number of extra bits (length / distance), or index bits of the second-level table (K_SUB)
+//   [12:10] kind
+//   [31:16] literal byte, length base, distance base, code-length symbol, or the second-level
+//           table's offset in WaveLds::tab
+enum : u32 { K_LIT = 0, K_LEN = 1, K_DIST = 2, K_SUB = 3, K_EOB = 4, K_INVALID = 5 };
 enum : int { T_LIT = 0, T_DIST = 1, T_CLEN = 2 };
 
-__device__ __forceinline__ u32 mk_entry(u32 nbits, u32 kind, u32 extra, u32 val) {
-    return nbits | (kind << 5) | (extra << 8) | (val << 16);
+__device__ __forceinline__ u32 mk_entry(u32 code_bits, u32 kind, u32 extra, u32 val) {
+    const u32 take = (kind == K_LEN || kind == K_DIST) ? code_bits + extra : code_bits;
+    return take | (extra << 5) | (kind << 10) | (val << 16);
 }
-__device__ __forceinline__ u32 e_nbits(u32 e) { return e & 31; }
-__device__ __forceinline__ u32 e_kind(u32 e) { return (e >> 5) & 7; }
-__device__ __forceinline__ u32 e_extra(u32 e) { return (e >> 8) & 31; }
+__device__ __forceinline__ u32 e_take(u32 e) { return e & 31; }
+__device__ __forceinline__ u32 e_extra(u32 e) { return (e >> 5) & 31; }
+__device__ __forceinline__ u32 e_kind(u32 e) { return (e >> 10) & 7; }
 __device__ __forceinline__ u32 e_val(u32 e) { return e >> 16; }
 
 // Symbol -> entry.  lenRanges / distRanges of flate/prefix.go:23-32 in closed form.
@@ -108,21 +112,26 @@ __device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
         if (sym == 256) return mk_entry(nbits, K_EOB, 0, 0);
         if (sym >= 286) return mk_entry(nbits, K_INVALID, 0, 0);      // flate/reader.go:228-229
         u32 s = sym - 257;
-        if (s < 8) return mk_entry(nbits, K_BASE, 0, 3 + s);
-        if (s == 28) return mk_entry(nbits, K_BASE, 0, 258);
+        if (s < 8) return mk_entry(nbits, K_LEN, 0, 3 + s);
+        if (s == 28) return mk_entry(nbits, K_LEN, 0, 258);
         u32 e = (s - 4) >> 2;
-        return mk_entry(nbits, K_BASE, e, 3 + ((4 + (s & 3)) << e));
+        return mk_entry(nbits, K_LEN, e, 3 + ((4 + (s & 3)) << e));
     } else if (type == T_DIST) {
         if (sym >= 30) return mk_entry(nbits, K_INVALID, 0, 0);       // flate/reader.go:212-214
-        if (sym < 4) return mk_entry(nbits, K_BASE, 0, 1 + sym);
+        if (sym < 4) return mk_entry(nbits, K_DIST, 0, 1 + sym);
         u32 e = (sym - 2) >> 1;
-        return mk_entry(nbits, K_BASE, e, 1 + ((2 + (sym & 1)) << e));
+        return mk_entry(nbits, K_DIST, e, 1 + ((2 + (sym & 1)) << e));
     } else {
         if (sym >= 19) return mk_entry(nbits, K_INVALID, 0, 0);       // flate/prefix.go:150-152
         return mk_entry(nbits, K_LIT, 0, sym);
     }
 }
 
+// ---- optional in-kernel profile (diagnostic build only: make prof) -------------
+// Cycle and event counters per phase, summed over all waves into a small global array
+// that no other code reads.  The production build compiles all of this away.
+enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
+       PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS, PF_COUNTERS = 16 };
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -144,19 +153,19 @@ struct WaveLds {
     };
     u32 tok[TOK_MAX];               // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
     u16 tdst[TOK_MAX];              // their destinations in the output window
+#ifdef XFG_PROFILE
+    unsigned long long prof[PF_COUNTERS];
+#endif
 };
 static_assert(sizeof(HeaderScratch) <= OUT_LDS, "header scratch must fit the output window");
 
-// ---- optional in-kernel profile (diagnostic build only: make prof) -------------
-// Cycle and event counters per phase, summed over all waves into a small global array
-// that no other code reads.  The production build compiles all of this away.
-enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
-       PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS, PF_COUNTERS = 16 };
 #ifdef XFG_PROFILE
+// Accumulated per wave in LDS (WaveLds::prof) and added to the global array once per chunk,
+// so that the instrumentation puts no memory traffic into the phases it times.
 __device__ unsigned long long g_prof[PF_COUNTERS];
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_amdgcn_s_memtime()
-#define PROF_ADD(slot, lane_) do { if ((lane_) == 0) atomicAdd(&g_prof[slot], __builtin_amdgcn_s_memtime() - prof_t0_); } while (0)
-#define PROF_CNT(slot, v, lane_) do { if ((lane_) == 0) atomicAdd(&g_prof[slot], (unsigned long long)(v)); } while (0)
+#define PROF_ADD(slot, lane_) do { if ((lane_) == 0) L.prof[slot] += __builtin_amdgcn_s_memtime() - prof_t0_; } while (0)
+#define PROF_CNT(slot, v, lane_) do { if ((lane_) == 0) L.prof[slot] += (unsigned long long)(v); } while (0)
 #else
 #define PROF_T0() do {} while (0)
 #define PROF_ADD(slot, lane_) do {} while (0)
@@ -395,13 +404,13 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
             const u32 my_off = next + incl - size;
             next += uni(__shfl(incl, 63));
             if (act) {
-                tab[__brev(u) >> (32 - ROOT)] = mk_entry(0, K_SUB, sb, my_off + TAB_OFF);   // offset in WaveLds::tab
+                tab[__brev(u) >> (32 - ROOT)] = mk_entry(ROOT, K_SUB, sb, my_off + TAB_OFF);   // offset in WaveLds::tab
                 for (u32 v = 0; v < (1u << sb); v++) {
                     const u32 w = (u << sb) | v;                // (ROOT+sb)-bit code space, MSB-first
                     u32 l = ROOT + 1;
                     while (l < ROOT + sb && (w >> (ROOT + sb - l)) >= L.h.first[l] + L.h.cnt[l]) l++;
                     const u32 sym = L.h.sorted[L.h.offs[l] + (w >> (ROOT + sb - l)) - L.h.first[l]];
-                    tab[my_off + (__brev(v) >> (32 - sb))] = sym_entry(TYPE, sym, l);
+                    tab[my_off + (__brev(v) >> (32 - sb))] = sym_entry(TYPE, sym, l - ROOT);  // the link consumed ROOT bits
                 }
             }
         }
@@ -410,13 +419,9 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
     return 0;
 }
 
-// Table lookup at the head of the bit buffer (TryReadSymbol/ReadSymbol, prefix/reader.go:183-221).
-template <int ROOT>
-__device__ __forceinline__ u32 lookup(const u32 *tab, u64 bitbuf) {
-    u32 e = uni(tab[(u32)bitbuf & ((1u << ROOT) - 1)]);
-    if (e_kind(e) == K_SUB)
-        e = uni(tab[e_val(e) + (((u32)(bitbuf >> ROOT)) & ((1u << e_extra(e)) - 1))]);
-    return e;
+// Lookup at the head of the bit buffer in the code-length code's table (codes <= 7 bits: one level).
+__device__ __forceinline__ u32 lookup_clen(const u32 *tab, u64 bitbuf) {
+    return uni(tab[(u32)bitbuf & ((1u << CLEN_ROOT) - 1)]);
 }
 
 struct Out {
@@ -501,9 +506,9 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
     for (u32 sym = 0; sym < max_syms;) {
         if (cst == 1) return XFG_ST_CORRUPTED;                  // "decode with empty prefix tree"
         if (r.bitcnt < 32) refill(r);
-        const u32 e = lookup<CLEN_ROOT>(L.h.clen, r.bitbuf);
-        if ((i32)e_nbits(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
-        consume(r, e_nbits(e));
+        const u32 e = lookup_clen(L.h.clen, r.bitbuf);
+        if ((i32)e_take(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
+        consume(r, e_take(e));
         if (e_kind(e) == K_INVALID) return XFG_ST_CORRUPTED;    // the degenerate filler symbol
         const u32 c = e_val(e);
         if (c < 16) {
@@ -616,10 +621,12 @@ __device__ __forceinline__ void store_batch_window(WaveLds &L, u32 lane, const u
 }
 
 // Decode the tokens that START in [start, seg_end), or until the lane's output cap.
-// One table lookup per iteration: a lane is at a literal/length root entry, at a distance
-// root entry or at a second-level entry; which one is per-lane state (tbase/tshift/twidth,
-// in_dist), so lanes in different states still share the instruction stream.
-// The bit buffer holds >= 56 valid bits at every lookup; one step consumes <= 28.
+// One table lookup per step, the same instruction stream for every lane whatever it is
+// looking at: the entry says what the step is (literal, length, distance, link to a
+// second-level table) and the lane's next lookup (tbase, twidth) follows from it by selects,
+// not branches.  Only what ends the lane (end of block, invalid code, end of input, distance
+// beyond the history) leaves the straight line.  The bit buffer is topped up to >= 56 valid
+// bits every two steps; one step consumes <= 28.
 //   EMIT = false: count only.  EMIT = true: literals go to the LDS output window at orel..
 //   (obase = the same position counted from the start of the chunk), matches to tok/tdst at moff..
 //   TAIL = true: the batch may run past the end of the stream; every read of the reference
@@ -636,70 +643,66 @@ __device__ __forceinline__ Seg decode_segment(WaveLds &L, i32 wb0, u32 start, u3
     wp += 7;
     u64 nextw = lds_load64(win + wp);
     u32 pos = start, nout = 0, nm = 0, flag = F_NONE;
-    u32 tbase = 0, tshift = 0, twidth = LIT_ROOT;
-    u32 len = 0;
-    bool in_dist = false;
+    u32 tbase = 0, twidth = LIT_ROOT, len = 0;
     for (;;) {
-        // top up to >= 56 bits; the following 8 bytes are already on their way for the next top-up
+        // top up; the 8 bytes after it are already on their way for the next top-up
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
         cnt |= 56;
         nextw = lds_load64(win + wp);
-        const u32 lo = (u32)buf;
-        const u32 e = L.tab[tbase + ((lo >> tshift) & ((1u << twidth) - 1))];
-        const u32 kind = e_kind(e);
-        if (kind == K_SUB) {                                    // second-level table: look again, nothing consumed
-            tbase = e_val(e);
-            twidth = e_extra(e);
-            tshift = in_dist ? (u32)DIST_ROOT : (u32)LIT_ROOT;
-            continue;
-        }
-        tshift = 0;
-        u32 n = e_nbits(e);
-        if (TAIL && pos + n > total_bits) { flag = F_EOF; break; }
-        bool done;                                              // a token boundary has been reached
-        if (!in_dist) {
-            if (kind == K_LIT) {
-                if (EMIT) outw[orel + nout] = (u8)e_val(e);
-                nout++;
-                tbase = 0; twidth = LIT_ROOT;
-                done = true;
-            } else if (kind == K_BASE) {
-                const u32 xb = e_extra(e);
-                if (TAIL && pos + n + xb > total_bits) { pos += n; flag = F_EOF; break; }
-                len = e_val(e) + ((lo >> n) & ((1u << xb) - 1));
-                n += xb;
-                if (dist_empty) { pos += n; flag = F_CORRUPT; break; }  // decode with empty prefix tree
-                in_dist = true;
-                tbase = LIT_TAB; twidth = DIST_ROOT;
-                done = false;
-            } else {
-                pos += n;
-                flag = (kind == K_EOB) ? F_EOB : F_CORRUPT;     // 286/287 or the degenerate filler
-                break;
-            }
-        } else {
-            if (kind != K_BASE) { pos += n; flag = F_CORRUPT; break; }   // distance symbols 30/31 or the filler
-            const u32 dxb = e_extra(e);
-            if (TAIL && pos + n + dxb > total_bits) { pos += n; flag = F_EOF; break; }
-            const u32 dist = e_val(e) + ((lo >> n) & ((1u << dxb) - 1));
-            n += dxb;
+#pragma unroll
+        for (int step = 0; step < 2; step++) {
+            const u32 lo = (u32)buf;
+            const u32 e = L.tab[tbase + (lo & ((1u << twidth) - 1))];
+            const u32 take = e_take(e), xb = e_extra(e), kind = e_kind(e), val = e_val(e);
+            const u32 value = val + ((lo >> (take - xb)) & ((1u << xb) - 1));   // length or distance
+            const bool is_lit = kind == K_LIT, is_len = kind == K_LEN, is_dist = kind == K_DIST, is_sub = kind == K_SUB;
+            bool rare = kind >= K_EOB || (dist_empty && is_len);
+            if (TAIL) rare = rare || pos + take > total_bits;
             if (EMIT) {
                 const u32 dst = obase + nout;
-                const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;       // dictDecoder.HistSize
-                if (dist > hist) { pos += n; flag = F_DIST; err_out = nout; break; }   // flate/reader.go:223-225
-                L.tok[moff + nm] = (len - 3) | ((dist - 1) << 8);
-                L.tdst[moff + nm] = (u16)(orel + nout);
+                const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;      // dictDecoder.HistSize
+                rare = rare || (is_dist && value > hist);
             }
-            nout += len; nm++;
-            in_dist = false;
-            tbase = 0; twidth = LIT_ROOT;
-            done = true;
-            if (nout >= (u32)OUT_CAP) { buf >>= n; cnt -= n; pos += n; break; }  // behaves like a segment end
+            if (rare) {                                         // this lane is finished
+                if (TAIL && pos + take > total_bits) {
+                    // io.ErrUnexpectedEOF: which read of the reference came up short?
+                    const u32 code = take - ((is_len || is_dist) ? xb : 0);
+                    if (pos + code > total_bits) {
+                        // the code word: nothing of it is consumed, second-level steps included
+                        if (tbase >= (u32)(1 << LIT_ROOT) && tbase < (u32)LIT_TAB) pos -= LIT_ROOT;
+                        else if (tbase >= (u32)(LIT_TAB + (1 << DIST_ROOT))) pos -= DIST_ROOT;
+                    } else {
+                        pos += code;                            // the extra bits
+                    }
+                    flag = F_EOF;
+                } else if (EMIT && is_dist) {
+                    pos += take;
+                    flag = F_DIST;                              // flate/reader.go:223-225
+                    err_out = nout;
+                } else {
+                    pos += take;
+                    flag = (kind == K_EOB) ? F_EOB : F_CORRUPT; // 286/287, 30/31, the degenerate filler, empty distance tree
+                }
+                goto out;
+            }
+            if (EMIT) {
+                if (is_lit) outw[orel + nout] = (u8)val;
+                if (is_dist) {
+                    L.tok[moff + nm] = (len - 3) | ((value - 1) << 8);
+                    L.tdst[moff + nm] = (u16)(orel + nout);
+                }
+            }
+            tbase = is_sub ? val : (is_len ? (u32)LIT_TAB : 0u);
+            twidth = is_sub ? xb : (is_len ? (u32)DIST_ROOT : (u32)LIT_ROOT);
+            len = is_len ? value : len;
+            nout += is_lit ? 1u : (is_dist ? len : 0u);
+            nm += is_dist ? 1u : 0u;
+            buf >>= take; cnt -= take; pos += take;
+            if ((is_lit || is_dist) && (pos >= seg_end || nout >= (u32)OUT_CAP)) goto out;   // a token boundary
         }
-        buf >>= n; cnt -= n; pos += n;
-        if (done && pos >= seg_end) break;
     }
+out:
     Seg r;
     r.end = pos; r.nout = nout; r.nmatch = nm; r.flag = flag;
     return r;
@@ -1113,6 +1116,11 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
         status = XFG_ST_SIZE_MISMATCH;                          // more output than the index promised
     }
     PROF_ADD(PF_TOTAL, lane);
+#ifdef XFG_PROFILE
+    wave_sync();
+    if (lane < PF_COUNTERS) { atomicAdd(&g_prof[lane], L.prof[lane]); L.prof[lane] = 0; }
+    wave_sync();
+#endif
     if (lane == 0) {
         xfg_result out;
         out.status = status;
@@ -1133,6 +1141,9 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
     const u32 wave = uni(threadIdx.x >> 6);
     const u32 lane = threadIdx.x & 63;
     WaveLds &L = lds[wave];
+#ifdef XFG_PROFILE
+    if (lane < PF_COUNTERS) L.prof[lane] = 0;
+#endif
     (void)scratch;
     // Static round-robin over the persistent grid: the trip count is provably wave-uniform.
     const u32 stride = gridDim.x * WAVES_PER_BLOCK;
