@@ -86,23 +86,26 @@ static_assert(TOK_MAX >= SEG_BITS / 2, "one lane's tokens (>= 2 bits each) must 
 static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
 
 // Table entry (u32): what one decode step does with the bits at the head of the buffer.
-//   [4:0]   bits to consume in this step: code word + extra bits (K_LEN / K_DIST), the code
-//           word (K_LIT / K_EOB / K_INVALID), or ROOT for a link to a second-level table (K_SUB);
+//   [4:0]   bits to consume in this step: code word + extra bits (length / distance), the code
+//           word (literal / end of block / invalid), or ROOT for a link to a second-level table;
 //           second-level entries hold what is left of the code word after ROOT bits
-//   [9:5]   number of extra bits (length / distance), or index bits of the second-level table (K_SUB)
-//   [12:10] kind
+//   [9:5]   number of extra bits (length / distance), or index bits of the second-level table (link)
+//   [15:10] what the step is, one bit each: E_LIT E_LEN E_DIST E_SUB E_STOP (end of block or
+//           invalid code: the lane is finished) E_EOB (with E_STOP: it is the end-of-block symbol)
 //   [31:16] literal byte, length base, distance base, code-length symbol, or the second-level
 //           table's offset in WaveLds::tab
 enum : u32 { K_LIT = 0, K_LEN = 1, K_DIST = 2, K_SUB = 3, K_EOB = 4, K_INVALID = 5 };
+enum : u32 { E_LIT = 1u << 10, E_LEN = 1u << 11, E_DIST = 1u << 12, E_SUB = 1u << 13, E_STOP = 1u << 14, E_EOB = 1u << 15 };
 enum : int { T_LIT = 0, T_DIST = 1, T_CLEN = 2 };
 
 __device__ __forceinline__ u32 mk_entry(u32 code_bits, u32 kind, u32 extra, u32 val) {
     const u32 take = (kind == K_LEN || kind == K_DIST) ? code_bits + extra : code_bits;
-    return take | (extra << 5) | (kind << 10) | (val << 16);
+    const u32 flags = kind == K_LIT ? E_LIT : kind == K_LEN ? E_LEN : kind == K_DIST ? E_DIST :
+                      kind == K_SUB ? E_SUB : kind == K_EOB ? (E_STOP | E_EOB) : E_STOP;
+    return take | (extra << 5) | flags | (val << 16);
 }
 __device__ __forceinline__ u32 e_take(u32 e) { return e & 31; }
 __device__ __forceinline__ u32 e_extra(u32 e) { return (e >> 5) & 31; }
-__device__ __forceinline__ u32 e_kind(u32 e) { return (e >> 10) & 7; }
 __device__ __forceinline__ u32 e_val(u32 e) { return e >> 16; }
 
 // Symbol -> entry.  lenRanges / distRanges of flate/prefix.go:23-32 in closed form.
@@ -148,7 +151,7 @@ struct WaveLds {
     u32 tab[LIT_TAB + DIST_TAB];    // literal/length table at 0, distance table at LIT_TAB
     u64 win[BWIN_BYTES / 8];        // batch window; its first WIN_BYTES double as the header reader's ring
     union {
-        u64 out[OUT_LDS / 8];       // output of the current batch, flushed to HBM with coalesced stores
+        u64 out[OUT_LDS / 8 + 8];   // output of the current batch, flushed to HBM with coalesced stores (+ 64 bytes nobody reads)
         HeaderScratch h;
     };
     u32 tok[TOK_MAX];               // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
@@ -509,7 +512,7 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
         const u32 e = lookup_clen(L.h.clen, r.bitbuf);
         if ((i32)e_take(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
         consume(r, e_take(e));
-        if (e_kind(e) == K_INVALID) return XFG_ST_CORRUPTED;    // the degenerate filler symbol
+        if (e & E_STOP) return XFG_ST_CORRUPTED;                // the degenerate filler symbol
         const u32 c = e_val(e);
         if (c < 16) {
             if (lane == 0) L.h.lens[sym] = (u8)c;
@@ -631,9 +634,9 @@ __device__ __forceinline__ void store_batch_window(WaveLds &L, u32 lane, const u
 //   (obase = the same position counted from the start of the chunk), matches to tok/tdst at moff..
 //   TAIL = true: the batch may run past the end of the stream; every read of the reference
 //   that can fail with io.ErrUnexpectedEOF is checked at the same point.
-template <bool EMIT, bool TAIL>
-__device__ __forceinline__ Seg decode_segment(WaveLds &L, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
-                                              bool dist_empty, u32 orel, u32 obase, u32 moff, u32 &err_out)
+template <bool EMIT>
+__device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
+                                                   bool dist_empty, u32 orel, u32 obase, u32 moff, u32 &err_out)
 {
     const u8 *win = reinterpret_cast<const u8 *>(L.win);
     u8 *outw = reinterpret_cast<u8 *>(L.out);
@@ -645,7 +648,78 @@ __device__ __forceinline__ Seg decode_segment(WaveLds &L, i32 wb0, u32 start, u3
     u32 pos = start, nout = 0, nm = 0, flag = F_NONE;
     u32 tbase = 0, twidth = LIT_ROOT, len = 0;
     for (;;) {
-        // top up; the 8 bytes after it are already on their way for the next top-up
+        buf |= nextw << cnt;
+        wp += (63 - cnt) >> 3;
+        cnt |= 56;
+        nextw = lds_load64(win + wp);
+        const u32 lo = (u32)buf;
+        const u32 e = L.tab[tbase + (lo & ((1u << twidth) - 1))];
+        const u32 take = e_take(e), xb = e_extra(e), val = e_val(e);
+        const u32 value = val + ((lo >> (take - xb)) & ((1u << xb) - 1));   // length or distance
+        const bool is_lit = (e & E_LIT) != 0, is_len = (e & E_LEN) != 0, is_dist = (e & E_DIST) != 0, is_sub = (e & E_SUB) != 0;
+        if (pos + take > total_bits) {
+            // io.ErrUnexpectedEOF: which read of the reference came up short?
+            const u32 code = take - ((is_len || is_dist) ? xb : 0);
+            if (pos + code > total_bits) {
+                // the code word: nothing of it is consumed, second-level steps included
+                if (tbase >= (u32)(1 << LIT_ROOT) && tbase < (u32)LIT_TAB) pos -= LIT_ROOT;
+                else if (tbase >= (u32)(LIT_TAB + (1 << DIST_ROOT))) pos -= DIST_ROOT;
+            } else {
+                pos += code;                                    // the extra bits
+            }
+            flag = F_EOF;
+            break;
+        }
+        if ((e & E_STOP) || (dist_empty && is_len)) {
+            pos += take;
+            flag = (e & E_EOB) ? F_EOB : F_CORRUPT;             // 286/287, 30/31, the degenerate filler, empty distance tree
+            break;
+        }
+        if (EMIT) {
+            if (is_lit) outw[orel + nout] = (u8)val;
+            if (is_dist) {
+                const u32 dst = obase + nout;
+                const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;      // dictDecoder.HistSize
+                if (value > hist) { pos += take; flag = F_DIST; err_out = nout; break; }   // flate/reader.go:223-225
+                L.tok[moff + nm] = (len - 3) | ((value - 1) << 8);
+                L.tdst[moff + nm] = (u16)(orel + nout);
+            }
+        }
+        tbase = is_sub ? val : (is_len ? (u32)LIT_TAB : 0u);
+        twidth = is_sub ? xb : (is_len ? (u32)DIST_ROOT : (u32)LIT_ROOT);
+        if (is_len) len = value;
+        if (is_lit) nout++;
+        if (is_dist) { nout += len; nm++; }
+        buf >>= take; cnt -= take; pos += take;
+        if ((is_lit || is_dist) && (pos >= seg_end || nout >= (u32)OUT_CAP)) break;    // a token boundary
+    }
+    Seg r;
+    r.end = pos; r.nout = nout; r.nmatch = nm; r.flag = flag;
+    return r;
+}
+
+// The same for a batch that cannot run into the end of the stream (every batch of a chunk but
+// its last one or two): no end-of-input checks, and the step is straight-line integer
+// arithmetic -- the entry's flag bits become all-ones / all-zero masks that select the next
+// lookup and what to add to the counters -- with one exit test per step and two steps per
+// top-up of the bit buffer.
+template <bool EMIT>
+__device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 start, u32 seg_end,
+                                                   bool dist_empty, u32 orel, u32 obase, u32 moff, u32 lane, u32 &err_out)
+{
+    const u8 *win = reinterpret_cast<const u8 *>(L.win);
+    u8 *outw = reinterpret_cast<u8 *>(L.out);
+    u32 wp = (u32)((i32)(start >> 3) - wb0);
+    u64 buf = lds_load64(win + wp) >> (start & 7);
+    u32 cnt = 56 - (start & 7);
+    wp += 7;
+    u64 nextw = lds_load64(win + wp);
+    u32 pos = start, nout = 0, nm = 0, len = 0;
+    u32 tbase = 0, twidth = LIT_ROOT;
+    u32 e = 0, bad = 0;
+    const u32 se1 = seg_end - 1;
+    const u32 stopmask = dist_empty ? (u32)(E_STOP | E_LEN) : (u32)E_STOP;      // wave-uniform
+    for (;;) {
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
         cnt |= 56;
@@ -653,56 +727,41 @@ __device__ __forceinline__ Seg decode_segment(WaveLds &L, i32 wb0, u32 start, u3
 #pragma unroll
         for (int step = 0; step < 2; step++) {
             const u32 lo = (u32)buf;
-            const u32 e = L.tab[tbase + (lo & ((1u << twidth) - 1))];
-            const u32 take = e_take(e), xb = e_extra(e), kind = e_kind(e), val = e_val(e);
-            const u32 value = val + ((lo >> (take - xb)) & ((1u << xb) - 1));   // length or distance
-            const bool is_lit = kind == K_LIT, is_len = kind == K_LEN, is_dist = kind == K_DIST, is_sub = kind == K_SUB;
-            bool rare = kind >= K_EOB || (dist_empty && is_len);
-            if (TAIL) rare = rare || pos + take > total_bits;
+            e = L.tab[tbase + __builtin_amdgcn_ubfe(lo, 0u, twidth)];
+            const u32 take = e & 31, xb = __builtin_amdgcn_ubfe(e, 5u, 5u), val = e >> 16;
+            const u32 value = val + __builtin_amdgcn_ubfe(lo, take - xb, xb);   // length or distance
+            const u32 m_lit = (u32)__builtin_amdgcn_sbfe((int)e, 10u, 1u);      // all ones or zero
+            const u32 m_len = (u32)__builtin_amdgcn_sbfe((int)e, 11u, 1u);
+            const u32 m_dist = (u32)__builtin_amdgcn_sbfe((int)e, 12u, 1u);
+            const u32 m_sub = (u32)__builtin_amdgcn_sbfe((int)e, 13u, 1u);
             if (EMIT) {
-                const u32 dst = obase + nout;
-                const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;      // dictDecoder.HistSize
-                rare = rare || (is_dist && value > hist);
-            }
-            if (rare) {                                         // this lane is finished
-                if (TAIL && pos + take > total_bits) {
-                    // io.ErrUnexpectedEOF: which read of the reference came up short?
-                    const u32 code = take - ((is_len || is_dist) ? xb : 0);
-                    if (pos + code > total_bits) {
-                        // the code word: nothing of it is consumed, second-level steps included
-                        if (tbase >= (u32)(1 << LIT_ROOT) && tbase < (u32)LIT_TAB) pos -= LIT_ROOT;
-                        else if (tbase >= (u32)(LIT_TAB + (1 << DIST_ROOT))) pos -= DIST_ROOT;
-                    } else {
-                        pos += code;                            // the extra bits
-                    }
-                    flag = F_EOF;
-                } else if (EMIT && is_dist) {
-                    pos += take;
-                    flag = F_DIST;                              // flate/reader.go:223-225
-                    err_out = nout;
-                } else {
-                    pos += take;
-                    flag = (kind == K_EOB) ? F_EOB : F_CORRUPT; // 286/287, 30/31, the degenerate filler, empty distance tree
-                }
-                goto out;
-            }
-            if (EMIT) {
-                if (is_lit) outw[orel + nout] = (u8)val;
-                if (is_dist) {
+                // a literal goes to its place; every other step writes a byte nobody reads
+                outw[(m_lit & (orel + nout)) | (~m_lit & ((u32)OUT_LDS + lane))] = (u8)val;
+                if (m_dist) {
+                    const u32 dst = obase + nout;
+                    const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;  // dictDecoder.HistSize
+                    bad = value > hist ? 1u : 0u;                                // flate/reader.go:223-225
                     L.tok[moff + nm] = (len - 3) | ((value - 1) << 8);
                     L.tdst[moff + nm] = (u16)(orel + nout);
                 }
             }
-            tbase = is_sub ? val : (is_len ? (u32)LIT_TAB : 0u);
-            twidth = is_sub ? xb : (is_len ? (u32)DIST_ROOT : (u32)LIT_ROOT);
-            len = is_len ? value : len;
-            nout += is_lit ? 1u : (is_dist ? len : 0u);
-            nm += is_dist ? 1u : 0u;
+            tbase = (val & m_sub) | (~m_sub & ((u32)LIT_TAB & m_len));
+            twidth = (xb & m_sub) | (~m_sub & ((u32)LIT_ROOT - (m_len & (u32)(LIT_ROOT - DIST_ROOT))));
+            len = (value & m_len) | (len & ~m_len);
+            nout += (len & m_dist) - m_lit;                     // a literal adds one, a finished match its length
+            nm -= m_dist;
             buf >>= take; cnt -= take; pos += take;
-            if ((is_lit || is_dist) && (pos >= seg_end || nout >= (u32)OUT_CAP)) goto out;   // a token boundary
+            // finished: a token boundary at or past the segment end or the output cap, or an entry that ends the lane
+            const u32 over = (se1 - pos) | ((u32)(OUT_CAP - 1) - nout);
+            const u32 stop = (over & (m_lit | m_dist)) | (0u - (e & stopmask)) | (0u - bad);
+            if ((i32)stop < 0) goto out;
         }
     }
 out:
+    u32 flag = F_NONE;
+    if (e & E_STOP) flag = (e & E_EOB) ? F_EOB : F_CORRUPT;     // 286/287, 30/31, the degenerate filler
+    else if (dist_empty && (e & E_LEN)) flag = F_CORRUPT;       // decode with empty prefix tree
+    else if (EMIT && bad) { nout -= len; nm--; flag = F_DIST; err_out = nout; }
     Seg r;
     r.end = pos; r.nout = nout; r.nmatch = nm; r.flag = flag;
     return r;
@@ -895,8 +954,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         u32 verified = 64;
         for (int pass = 1;; pass++) {
             if (dirty && !dead) {
-                if (tail) sg = decode_segment<false, true>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
-                else      sg = decode_segment<false, false>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
+                if (tail) sg = decode_segment_tail<false>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
+                else      sg = decode_segment_fast<false>(L, wb0, start, seg_end, dist_empty, 0, 0, 0, lane, dummy);
             }
             PROF_CNT(PF_N_PASS, 1, lane);
             const u32 pe = __shfl_up(sg.end, 1);
@@ -942,8 +1001,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         {
             PROF_T0();
             if (keep) {
-                if (tail) fin = decode_segment<true, true>(L, wb0, start, seg_end, total_bits, dist_empty, rel, o.pos + rel, moff, err_out);
-                else      fin = decode_segment<true, false>(L, wb0, start, seg_end, total_bits, dist_empty, rel, o.pos + rel, moff, err_out);
+                if (tail) fin = decode_segment_tail<true>(L, wb0, start, seg_end, total_bits, dist_empty, rel, o.pos + rel, moff, err_out);
+                else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, dist_empty, rel, o.pos + rel, moff, lane, err_out);
             }
             wave_sync();
             PROF_ADD(PF_EMIT, lane);
