@@ -47,7 +47,7 @@ SYMBOLS = [
     "xfg_decode", "xfg_decode_device", "xfg_sync",
     "xfg_reader_new", "xfg_reader_reset", "xfg_reader_read", "xfg_reader_seek", "xfg_reader_close",
     "xfg_reader_free", "xfg_reader_num_records", "xfg_reader_get_records", "xfg_reader_bytes_read",
-    "xfg_reader_set_window", "xfg_index_parse", "xfg_flate_decode",
+    "xfg_reader_set_window", "xfg_index_parse", "xfg_shard_plan", "xfg_flate_decode",
 ]
 
 _lib = None
@@ -89,6 +89,7 @@ def lib():
     L.xfg_reader_bytes_read.restype = i64
     L.xfg_reader_set_window.argtypes = [vp, i64]
     L.xfg_index_parse.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
+    L.xfg_shard_plan.argtypes = [vp, sz, ctypes.c_int, ctypes.POINTER(sz)]
     L.xfg_flate_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(i64), ctypes.POINTER(i64),
                                    ctypes.POINTER(ctypes.c_int)]
     _lib = L
@@ -160,3 +161,12 @@ def index_parse(stream):
     arr = (Chunk * max(n.value, 1))()
     err = lib().xfg_index_parse(stream, len(stream), arr, n.value, ctypes.byref(n))
     return err, [arr[i] for i in range(n.value)]
+
+
+def shard_plan(chunks, n_shards):
+    """xfg_shard_plan: -> [first_0, ..., first_n_shards]; shard k owns records [first[k], first[k+1])."""
+    n = len(chunks)
+    arr = (Chunk * max(n, 1))(*chunks)
+    first = (ctypes.c_size_t * (n_shards + 1))()
+    check(lib().xfg_shard_plan(arr, n, n_shards, first), "xfg_shard_plan")
+    return list(first)

@@ -779,3 +779,30 @@ extern "C" int xfg_index_parse(const uint8_t *stream, size_t len, xfg_chunk *chu
     if (n > cap) *n_out = n;
     return XFG_ERR_NONE;
 }
+
+// Index-range sharding: cut the chunk table into n_shards contiguous
+// record ranges of about equal work, work = comp_size + raw_size (the bytes a GPU reads and
+// writes for the chunk).  Shard k owns records [first[k], first[k+1]).  Records are never
+// split, every record belongs to exactly one shard, and a shard may be empty when there are
+// fewer records than shards.  Host only; deterministic, so every rank computes the same plan.
+extern "C" int xfg_shard_plan(const xfg_chunk *chunks, size_t n, int n_shards, size_t *first) {
+    if ((!chunks && n) || !first || n_shards <= 0) return XFG_E_ARG;
+    unsigned __int128 total = 0;
+    for (size_t i = 0; i < n; i++) total += (unsigned __int128)chunks[i].comp_size + chunks[i].raw_size;
+    first[0] = 0;
+    size_t i = 0;
+    unsigned __int128 done = 0;
+    for (int k = 1; k < n_shards; k++) {
+        // the boundary after shard k-1: the first record whose start reaches k/n_shards of the work
+        const unsigned __int128 want = total * (unsigned)k / (unsigned)n_shards;
+        while (i < n && done < want) {
+            const unsigned __int128 w = (unsigned __int128)chunks[i].comp_size + chunks[i].raw_size;
+            if (done + w / 2 > want) break;                 // nearer to the boundary without this record
+            done += w;
+            i++;
+        }
+        first[k] = i;
+    }
+    first[n_shards] = n;
+    return XFG_OK;
+}

@@ -197,6 +197,18 @@ int xfg_reader_set_window(xfg_reader *r, int64_t max_raw_bytes);
 int xfg_index_parse(const uint8_t *stream, size_t len, xfg_chunk *chunks, size_t cap, size_t *n_out);
 
 /*
+ * Index-range sharding over the GPUs of a node.  The reference reads chunks one
+ * after the other (xflate/reader.go:183-212) although they are independent
+ * (xflate/index.go:27-31 gives every chunk's input and output range up front);
+ * this cuts the chunk table into n_shards contiguous record ranges of about
+ * equal comp_size + raw_size.  first[] has n_shards + 1 entries; shard k owns
+ * records [first[k], first[k+1]).  Host only, deterministic: every process of
+ * a one-process-per-GPU job computes the same plan and takes the range of its
+ * rank; no data-path collective is involved.  Returns an XFG_E_* code.
+ */
+int xfg_shard_plan(const xfg_chunk *chunks, size_t n, int n_shards, size_t *first);
+
+/*
  * flate.NewReader(r, nil) + ReadAll + Close in one call (flate/reader.go:39-97)
  * for an in-memory stream: inflates one plain DEFLATE stream on the device
  * with the in-repo flate package's semantics.  *err = XFG_ERR_NONE (clean
