@@ -147,11 +147,12 @@ struct HeaderScratch {
     u32 offs[16];           // index in sorted[] of the first symbol of each length
     u32 endr[16];           // end of the length-l codes in ROOT-bit code space (l <= ROOT)
 };
-struct WaveLds {
+struct alignas(16) WaveLds {
     u32 tab[LIT_TAB + DIST_TAB];    // literal/length table at 0, distance table at LIT_TAB
     u64 win[BWIN_BYTES / 8];        // batch window; its first WIN_BYTES double as the header reader's ring
     union {
-        u64 out[OUT_LDS / 8 + 8];   // output of the current batch, flushed to HBM with coalesced stores (+ 64 bytes nobody reads)
+        u64 out[OUT_LDS / 8 + 10];  // output of the current batch at [woff, woff + n), woff = its HBM address mod 16, so that
+                                    // the flush is 16-byte aligned on both sides (+ 64 bytes that nobody reads)
         HeaderScratch h;
     };
     u32 tok[TOK_MAX];               // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
@@ -568,18 +569,24 @@ struct Seg {
     u32 flag;       // F_*: why the lane stopped before its segment end
 };
 
-__device__ __forceinline__ u64 lds_load64(const u8 *p) {
-    u64 v;
-    __builtin_memcpy(&v, p, 8);                                 // ds_read_b64, any byte alignment
-    return v;
-}
+// LDS accesses at any byte alignment.  A 64-bit (or wider) DS access off its natural alignment
+// is replayed at ~64 cycles per wave-instruction on gfx950, so the bit buffer is fed from
+// aligned dwords put together with v_alignbyte, and byte-granular copies use 32-bit accesses.
 __device__ __forceinline__ u32 lds_load32(const u8 *p) {
     u32 v;
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-__device__ __forceinline__ void lds_store64(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
 __device__ __forceinline__ void lds_store32(u8 *p, u32 v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void no_merge() { asm volatile("" ::: "memory"); }   // keeps adjacent 32-bit accesses apart
+// The 8 bytes at byte position bytepos of the window (three aligned dwords, funnel-shifted).
+__device__ __forceinline__ u64 win_load64(const u32 *w32, u32 bytepos) {
+    const u32 i = bytepos >> 2;
+    const u32 d0 = w32[i], d1 = w32[i + 1], d2 = w32[i + 2];
+    const u32 lo = __builtin_amdgcn_alignbyte(d1, d0, bytepos & 3);
+    const u32 hi = __builtin_amdgcn_alignbyte(d2, d1, bytepos & 3);
+    return ((u64)hi << 32) | lo;
+}
 
 // The compressed bytes [wb0, wb0 + BWIN_BYTES) of the virtual stream, 16 bytes per lane and
 // unit, into registers.  wb0 (may be negative by < 16) is chosen so that the global address
@@ -638,20 +645,20 @@ template <bool EMIT>
 __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
                                                    bool dist_empty, u32 orel, u32 obase, u32 moff, u32 &err_out)
 {
-    const u8 *win = reinterpret_cast<const u8 *>(L.win);
+    const u32 *win = reinterpret_cast<const u32 *>(L.win);
     u8 *outw = reinterpret_cast<u8 *>(L.out);
     u32 wp = (u32)((i32)(start >> 3) - wb0);
-    u64 buf = lds_load64(win + wp) >> (start & 7);
+    u64 buf = win_load64(win, wp) >> (start & 7);
     u32 cnt = 56 - (start & 7);                                 // account 7 of the 8 bytes: cnt stays below 64
     wp += 7;
-    u64 nextw = lds_load64(win + wp);
+    u64 nextw = win_load64(win, wp);
     u32 pos = start, nout = 0, nm = 0, flag = F_NONE;
     u32 tbase = 0, twidth = LIT_ROOT, len = 0;
     for (;;) {
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
         cnt |= 56;
-        nextw = lds_load64(win + wp);
+        nextw = win_load64(win, wp);
         const u32 lo = (u32)buf;
         const u32 e = L.tab[tbase + (lo & ((1u << twidth) - 1))];
         const u32 take = e_take(e), xb = e_extra(e), val = e_val(e);
@@ -707,13 +714,13 @@ template <bool EMIT>
 __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 start, u32 seg_end,
                                                    bool dist_empty, u32 orel, u32 obase, u32 moff, u32 lane, u32 &err_out)
 {
-    const u8 *win = reinterpret_cast<const u8 *>(L.win);
+    const u32 *win = reinterpret_cast<const u32 *>(L.win);
     u8 *outw = reinterpret_cast<u8 *>(L.out);
     u32 wp = (u32)((i32)(start >> 3) - wb0);
-    u64 buf = lds_load64(win + wp) >> (start & 7);
+    u64 buf = win_load64(win, wp) >> (start & 7);
     u32 cnt = 56 - (start & 7);
     wp += 7;
-    u64 nextw = lds_load64(win + wp);
+    u64 nextw = win_load64(win, wp);
     u32 pos = start, nout = 0, nm = 0, len = 0;
     u32 tbase = 0, twidth = LIT_ROOT;
     u32 e = 0, bad = 0;
@@ -723,7 +730,7 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 star
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
         cnt |= 56;
-        nextw = lds_load64(win + wp);
+        nextw = win_load64(win, wp);
 #pragma unroll
         for (int step = 0; step < 2; step++) {
             const u32 lo = (u32)buf;
@@ -736,7 +743,7 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 star
             const u32 m_sub = (u32)__builtin_amdgcn_sbfe((int)e, 13u, 1u);
             if (EMIT) {
                 // a literal goes to its place; every other step writes a byte nobody reads
-                outw[(m_lit & (orel + nout)) | (~m_lit & ((u32)OUT_LDS + lane))] = (u8)val;
+                outw[(m_lit & (orel + nout)) | (~m_lit & ((u32)OUT_LDS + 16 + lane))] = (u8)val;
                 if (m_dist) {
                     const u32 dst = obase + nout;
                     const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;  // dictDecoder.HistSize
@@ -793,15 +800,21 @@ __device__ __forceinline__ void mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// n <= 16 bytes LDS -> LDS, any alignment, ranges disjoint: both reads happen before both writes.
+// n <= 16 bytes LDS -> LDS, any alignment, ranges disjoint: all reads happen before the writes.
+// Pieces overlap instead of branching on the exact length.
 __device__ __forceinline__ void copy16_l2l(u8 *dst, const u8 *src, u32 n) {
     if (n >= 8) {
-        const u64 a = lds_load64(src), b = lds_load64(src + n - 8);
-        lds_store64(dst, a);
-        lds_store64(dst + n - 8, b);
+        const u32 a0 = lds_load32(src); no_merge();
+        const u32 a1 = lds_load32(src + 4); no_merge();
+        const u32 b0 = lds_load32(src + n - 8); no_merge();
+        const u32 b1 = lds_load32(src + n - 4); no_merge();
+        lds_store32(dst, a0); no_merge();
+        lds_store32(dst + 4, a1); no_merge();
+        lds_store32(dst + n - 8, b0); no_merge();
+        lds_store32(dst + n - 4, b1);
     } else if (n >= 4) {
         const u32 a = lds_load32(src), b = lds_load32(src + n - 4);
-        lds_store32(dst, a);
+        lds_store32(dst, a); no_merge();
         lds_store32(dst + n - 4, b);
     } else {                                                    // 1..3
         const u32 m = n > 1 ? 1u : 0u;
@@ -815,13 +828,15 @@ __device__ __forceinline__ void copy16_g2l(u8 *dst, const u8 *src, u32 n) {
         u64 a, b;
         __builtin_memcpy(&a, src, 8);
         __builtin_memcpy(&b, src + n - 8, 8);
-        lds_store64(dst, a);
-        lds_store64(dst + n - 8, b);
+        lds_store32(dst, (u32)a); no_merge();
+        lds_store32(dst + 4, (u32)(a >> 32)); no_merge();
+        lds_store32(dst + n - 8, (u32)b); no_merge();
+        lds_store32(dst + n - 4, (u32)(b >> 32));
     } else if (n >= 4) {
         u32 a, b;
         __builtin_memcpy(&a, src, 4);
         __builtin_memcpy(&b, src + n - 4, 4);
-        lds_store32(dst, a);
+        lds_store32(dst, a); no_merge();
         lds_store32(dst + n - 4, b);
     } else {
         const u32 m = n > 1 ? 1u : 0u;
@@ -839,8 +854,9 @@ __device__ __forceinline__ void copy16_g2l(u8 *dst, const u8 *src, u32 n) {
 // (all earlier rounds are complete, and every literal is in place), so every pass of the
 // inner loop retires at least that token.  A started copy never waits again: what it reads
 // beyond its foreign source bytes it has written itself.
-__device__ void resolve_tokens(const u8 *raw, u32 base, WaveLds &L, u32 M, u32 lane) {
+__device__ void resolve_tokens(const u8 *raw, u32 base, u32 woff, WaveLds &L, u32 M, u32 lane) {
     u8 *outw = reinterpret_cast<u8 *>(L.out);
+    const u8 *gwin = raw + base - woff;                         // HBM address of window position 0
     u32 rounds = 0;
     for (u32 r0 = 0; r0 < M; r0 += 64) {
         const u32 m = r0 + lane;
@@ -853,12 +869,12 @@ __device__ void resolve_tokens(const u8 *raw, u32 base, WaveLds &L, u32 M, u32 l
             dist = (t >> 8) + 1;
         }
         u32 cur = d, rem = len;
-        const i32 s = (i32)d - (i32)dist;                       // source start, window-relative
+        const i32 s = (i32)d - (i32)dist;                       // source start, window position
         // ---- bytes before the window
-        if (s < 0) {
-            u32 g = (u32)(-s);
+        if (have && s < (i32)woff) {
+            u32 g = (u32)((i32)woff - s);
             if (g > rem) g = rem;
-            const u8 *src = raw + base - (u32)(-s);             // >= raw: dist <= history was checked by the emitter
+            const u8 *src = gwin + s;                           // >= raw: dist <= history was checked by the emitter
             u32 off = 0;
             while (off < g) {
                 const u32 n = g - off < 16 ? g - off : 16;
@@ -895,20 +911,19 @@ __device__ void resolve_tokens(const u8 *raw, u32 base, WaveLds &L, u32 M, u32 l
     (void)rounds;
 }
 
-// Flush outw[0, n) to raw[base, base + n), coalesced 16-byte stores where the HBM address allows.
-__device__ void flush_output(u8 *raw, u32 base, const u8 *outw, u32 n, u32 lane) {
+// Flush window positions [woff, woff + n) to raw[base, base + n): woff is the HBM address mod 16,
+// so the 16-byte loads from LDS and the 16-byte stores to HBM are both aligned.
+__device__ void flush_output(u8 *raw, u32 base, const u8 *win0, u32 woff, u32 n, u32 lane) {
     u8 *g = raw + base;
-    u32 head = (u32)((16 - ((uintptr_t)g & 15)) & 15);
+    const u8 *w = win0 + woff;
+    u32 head = (16 - woff) & 15;
     if (head > n) head = n;
-    if (lane < head) g[lane] = outw[lane];
+    if (lane < head) g[lane] = w[lane];
     const u32 body = (n - head) >> 4;
-    for (u32 i = lane; i < body; i += 64) {
-        uint4 v;
-        __builtin_memcpy(&v, outw + head + i * 16, 16);
-        *reinterpret_cast<uint4 *>(g + head + i * 16) = v;
-    }
+    for (u32 i = lane; i < body; i += 64)
+        *reinterpret_cast<uint4 *>(g + head + i * 16) = *reinterpret_cast<const uint4 *>(w + head + i * 16);
     const u32 done = head + body * 16;
-    if (done + lane < n) g[done + lane] = outw[done + lane];
+    if (done + lane < n) g[done + lane] = w[done + lane];
 }
 
 struct BlockEnd {
@@ -996,13 +1011,14 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         }
 
         // ---- stage 1b: final pass, literals into the output window, matches to the token list
+        const u32 woff = (u32)((uintptr_t)(o.raw + o.pos) & 15);  // window position of the batch's first byte
         u32 err_out = 0;
         Seg fin = sg;
         {
             PROF_T0();
             if (keep) {
-                if (tail) fin = decode_segment_tail<true>(L, wb0, start, seg_end, total_bits, dist_empty, rel, o.pos + rel, moff, err_out);
-                else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, dist_empty, rel, o.pos + rel, moff, lane, err_out);
+                if (tail) fin = decode_segment_tail<true>(L, wb0, start, seg_end, total_bits, dist_empty, woff + rel, o.pos + rel, moff, err_out);
+                else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, dist_empty, woff + rel, o.pos + rel, moff, lane, err_out);
             }
             wave_sync();
             PROF_ADD(PF_EMIT, lane);
@@ -1021,7 +1037,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         if (M) {
             PROF_T0();
             mem_sync();                                         // earlier batches' flushed bytes are read back here
-            resolve_tokens(o.raw, o.pos, L, M, lane);
+            resolve_tokens(o.raw, o.pos, woff, L, M, lane);
             PROF_ADD(PF_RESOLVE, lane);
         }
         // ---- flush to HBM (never beyond the chunk's capacity)
@@ -1030,7 +1046,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             u32 nflush = total_out;
             if (o.pos >= o.cap) nflush = 0; else if (nflush > o.cap - o.pos) nflush = o.cap - o.pos;
             wave_sync();
-            flush_output(o.raw, o.pos, reinterpret_cast<const u8 *>(L.out), nflush, lane);
+            flush_output(o.raw, o.pos, reinterpret_cast<const u8 *>(L.out), woff, nflush, lane);
             wave_sync();
             PROF_ADD(PF_FLUSH, lane);
         }
