@@ -73,6 +73,9 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_TOK_MAX
 #define XFG_TOK_MAX 768
 #endif
+#ifndef XFG_ACCEPT_FD
+#define XFG_ACCEPT_FD 40              // after the second pass, settle for a verified prefix of this many lanes
+#endif
 constexpr int SEG_BITS = XFG_SEG_BITS;  // bits of compressed stream per lane and batch
 constexpr int BATCH_BYTES = 64 * SEG_BITS / 8;
 constexpr int BWIN_BYTES = (BATCH_BYTES + 64) > 1024 ? (BATCH_BYTES + 64) : 1024;   // batch window: 16-byte alignment slack + over-read; >= the header ring
@@ -93,15 +96,16 @@ static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
 //   [15:10] what the step is, one bit each: E_LIT E_LEN E_DIST E_SUB E_STOP (end of block or
 //           invalid code: the lane is finished) E_EOB (with E_STOP: it is the end-of-block symbol)
 //   [31:16] literal byte, length base, distance base, code-length symbol, or the second-level
-//           table's offset in WaveLds::tab
+//           table's BYTE offset in WaveLds::tab; bit 31 is set on E_STOP entries and on no other
 enum : u32 { K_LIT = 0, K_LEN = 1, K_DIST = 2, K_SUB = 3, K_EOB = 4, K_INVALID = 5 };
-enum : u32 { E_LIT = 1u << 10, E_LEN = 1u << 11, E_DIST = 1u << 12, E_SUB = 1u << 13, E_STOP = 1u << 14, E_EOB = 1u << 15 };
+enum : u32 { E_LIT = 1u << 10, E_LEN = 1u << 11, E_DIST = 1u << 12, E_SUB = 1u << 13, E_STOP = 1u << 14, E_EOB = 1u << 15,
+             E_SIGN = 1u << 31 };      // set with E_STOP (no other entry's value reaches bit 15): the exit test is a sign test
 enum : int { T_LIT = 0, T_DIST = 1, T_CLEN = 2 };
 
 __device__ __forceinline__ u32 mk_entry(u32 code_bits, u32 kind, u32 extra, u32 val) {
     const u32 take = (kind == K_LEN || kind == K_DIST) ? code_bits + extra : code_bits;
     const u32 flags = kind == K_LIT ? E_LIT : kind == K_LEN ? E_LEN : kind == K_DIST ? E_DIST :
-                      kind == K_SUB ? E_SUB : kind == K_EOB ? (E_STOP | E_EOB) : E_STOP;
+                      kind == K_SUB ? E_SUB : kind == K_EOB ? (E_STOP | E_EOB | E_SIGN) : (E_STOP | E_SIGN);
     return take | (extra << 5) | flags | (val << 16);
 }
 __device__ __forceinline__ u32 e_take(u32 e) { return e & 31; }
@@ -408,7 +412,7 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
             const u32 my_off = next + incl - size;
             next += uni(__shfl(incl, 63));
             if (act) {
-                tab[__brev(u) >> (32 - ROOT)] = mk_entry(ROOT, K_SUB, sb, my_off + TAB_OFF);   // offset in WaveLds::tab
+                tab[__brev(u) >> (32 - ROOT)] = mk_entry(ROOT, K_SUB, sb, 4 * (my_off + TAB_OFF));   // byte offset in WaveLds::tab
                 for (u32 v = 0; v < (1u << sb); v++) {
                     const u32 w = (u << sb) | v;                // (ROOT+sb)-bit code space, MSB-first
                     u32 l = ROOT + 1;
@@ -653,14 +657,14 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
     wp += 7;
     u64 nextw = win_load64(win, wp);
     u32 pos = start, nout = 0, nm = 0, flag = F_NONE;
-    u32 tbase = 0, twidth = LIT_ROOT, len = 0;
+    u32 tbase = 0, twidth = LIT_ROOT, len = 0;                  // tbase: byte offset in L.tab
     for (;;) {
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
         cnt |= 56;
         nextw = win_load64(win, wp);
         const u32 lo = (u32)buf;
-        const u32 e = L.tab[tbase + (lo & ((1u << twidth) - 1))];
+        const u32 e = L.tab[(tbase >> 2) + (lo & ((1u << twidth) - 1))];
         const u32 take = e_take(e), xb = e_extra(e), val = e_val(e);
         const u32 value = val + ((lo >> (take - xb)) & ((1u << xb) - 1));   // length or distance
         const bool is_lit = (e & E_LIT) != 0, is_len = (e & E_LEN) != 0, is_dist = (e & E_DIST) != 0, is_sub = (e & E_SUB) != 0;
@@ -669,8 +673,8 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
             const u32 code = take - ((is_len || is_dist) ? xb : 0);
             if (pos + code > total_bits) {
                 // the code word: nothing of it is consumed, second-level steps included
-                if (tbase >= (u32)(1 << LIT_ROOT) && tbase < (u32)LIT_TAB) pos -= LIT_ROOT;
-                else if (tbase >= (u32)(LIT_TAB + (1 << DIST_ROOT))) pos -= DIST_ROOT;
+                if (tbase >= 4u * (1 << LIT_ROOT) && tbase < 4u * LIT_TAB) pos -= LIT_ROOT;
+                else if (tbase >= 4u * (LIT_TAB + (1 << DIST_ROOT))) pos -= DIST_ROOT;
             } else {
                 pos += code;                                    // the extra bits
             }
@@ -692,7 +696,7 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
                 L.tdst[moff + nm] = (u16)(orel + nout);
             }
         }
-        tbase = is_sub ? val : (is_len ? (u32)LIT_TAB : 0u);
+        tbase = is_sub ? val : (is_len ? 4u * LIT_TAB : 0u);
         twidth = is_sub ? xb : (is_len ? (u32)DIST_ROOT : (u32)LIT_ROOT);
         if (is_len) len = value;
         if (is_lit) nout++;
@@ -710,31 +714,41 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
 // arithmetic -- the entry's flag bits become all-ones / all-zero masks that select the next
 // lookup and what to add to the counters -- with one exit test per step and two steps per
 // top-up of the bit buffer.
+typedef const __attribute__((address_space(3))) u32 *lds_cu32p;
+typedef const __attribute__((address_space(3))) u8 *lds_cu8p;
+struct __attribute__((packed)) PackedU64 { u64 v; };             // 8 bytes at any alignment
+typedef const __attribute__((address_space(3))) PackedU64 *lds_cpu64p;
+
 template <bool EMIT>
 __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 start, u32 seg_end,
-                                                   bool dist_empty, u32 orel, u32 obase, u32 moff, u32 lane, u32 &err_out)
+                                                   u32 orel, u32 obase, u32 moff, u32 lane, u32 &err_out)
 {
-    const u32 *win = reinterpret_cast<const u32 *>(L.win);
+    // LDS byte addresses: the lookup state is the address of the table the next step indexes
+    const u32 tab0 = (u32)(uintptr_t)(lds_cu32p)L.tab;
+    const u32 tab1 = tab0 + 4u * LIT_TAB;
+    const u32 win0 = (u32)(uintptr_t)(lds_cu8p)reinterpret_cast<const u8 *>(L.win);
     u8 *outw = reinterpret_cast<u8 *>(L.out);
-    u32 wp = (u32)((i32)(start >> 3) - wb0);
-    u64 buf = win_load64(win, wp) >> (start & 7);
-    u32 cnt = 56 - (start & 7);
+    u32 wp = win0 + (u32)((i32)(start >> 3) - wb0);
+    u64 nextw;
+    nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
+    u64 buf = nextw >> (start & 7);
+    u32 cnt = 56 - (start & 7);                                 // account 7 of the 8 bytes: cnt stays below 64
     wp += 7;
-    u64 nextw = win_load64(win, wp);
-    u32 pos = start, nout = 0, nm = 0, len = 0;
-    u32 tbase = 0, twidth = LIT_ROOT;
+    nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
+    u32 rem1 = seg_end - 1 - start;                             // bits to the segment end, minus one: negative = at or past it
+    u32 nout = 0, nm = 0, len = 0;
+    u32 tb = tab0, tw = LIT_ROOT;
     u32 e = 0, bad = 0;
-    const u32 se1 = seg_end - 1;
-    const u32 stopmask = dist_empty ? (u32)(E_STOP | E_LEN) : (u32)E_STOP;      // wave-uniform
     for (;;) {
+        // top up; the 8 bytes after it are already on their way for the next top-up
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
         cnt |= 56;
-        nextw = win_load64(win, wp);
+        nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
 #pragma unroll
         for (int step = 0; step < 2; step++) {
             const u32 lo = (u32)buf;
-            e = L.tab[tbase + __builtin_amdgcn_ubfe(lo, 0u, twidth)];
+            e = *(lds_cu32p)(uintptr_t)(tb + (__builtin_amdgcn_ubfe(lo, 0u, tw) << 2));
             const u32 take = e & 31, xb = __builtin_amdgcn_ubfe(e, 5u, 5u), val = e >> 16;
             const u32 value = val + __builtin_amdgcn_ubfe(lo, take - xb, xb);   // length or distance
             const u32 m_lit = (u32)__builtin_amdgcn_sbfe((int)e, 10u, 1u);      // all ones or zero
@@ -747,30 +761,30 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 star
                 if (m_dist) {
                     const u32 dst = obase + nout;
                     const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;  // dictDecoder.HistSize
-                    bad = value > hist ? 1u : 0u;                                // flate/reader.go:223-225
+                    bad = value > hist ? 0x80000000u : 0u;                       // flate/reader.go:223-225
                     L.tok[moff + nm] = (len - 3) | ((value - 1) << 8);
                     L.tdst[moff + nm] = (u16)(orel + nout);
                 }
             }
-            tbase = (val & m_sub) | (~m_sub & ((u32)LIT_TAB & m_len));
-            twidth = (xb & m_sub) | (~m_sub & ((u32)LIT_ROOT - (m_len & (u32)(LIT_ROOT - DIST_ROOT))));
+            tb = (m_sub & (val + tab0)) | (~m_sub & ((m_len & tab1) | (~m_len & tab0)));
+            tw = (m_sub & xb) | (~m_sub & ((u32)LIT_ROOT - (m_len & (u32)(LIT_ROOT - DIST_ROOT))));
             len = (value & m_len) | (len & ~m_len);
             nout += (len & m_dist) - m_lit;                     // a literal adds one, a finished match its length
             nm -= m_dist;
-            buf >>= take; cnt -= take; pos += take;
+            buf >>= take; cnt -= take; rem1 -= take;
             // finished: a token boundary at or past the segment end or the output cap, or an entry that ends the lane
-            const u32 over = (se1 - pos) | ((u32)(OUT_CAP - 1) - nout);
-            const u32 stop = (over & (m_lit | m_dist)) | (0u - (e & stopmask)) | (0u - bad);
+            const u32 over = rem1 | ((u32)(OUT_CAP - 1) - nout);
+            u32 stop = (over & (m_lit | m_dist)) | e;
+            if (EMIT) stop |= bad;
             if ((i32)stop < 0) goto out;
         }
     }
 out:
     u32 flag = F_NONE;
     if (e & E_STOP) flag = (e & E_EOB) ? F_EOB : F_CORRUPT;     // 286/287, 30/31, the degenerate filler
-    else if (dist_empty && (e & E_LEN)) flag = F_CORRUPT;       // decode with empty prefix tree
     else if (EMIT && bad) { nout -= len; nm--; flag = F_DIST; err_out = nout; }
     Seg r;
-    r.end = pos; r.nout = nout; r.nmatch = nm; r.flag = flag;
+    r.end = seg_end - 1 - rem1; r.nout = nout; r.nmatch = nm; r.flag = flag;
     return r;
 }
 
@@ -957,7 +971,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         have_pf = false;
         PROF_CNT(PF_N_BATCH, 1, lane);
         PROF_T0();
-        const bool tail = p0 + 64u * SEG_BITS + 64u > total_bits;      // wave-uniform
+        // wave-uniform: batches that may meet the end of the stream, and blocks without a distance code, go the careful way
+        const bool tail = dist_empty || p0 + 64u * SEG_BITS + 64u > total_bits;
 
         // ---- stage 1a: speculative passes until the chain of segment starts is stable
         u32 start = p0 + lane * SEG_BITS;
@@ -970,7 +985,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         for (int pass = 1;; pass++) {
             if (dirty && !dead) {
                 if (tail) sg = decode_segment_tail<false>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
-                else      sg = decode_segment_fast<false>(L, wb0, start, seg_end, dist_empty, 0, 0, 0, lane, dummy);
+                else      sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy);
             }
             PROF_CNT(PF_N_PASS, 1, lane);
             const u32 pe = __shfl_up(sg.end, 1);
@@ -985,7 +1000,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             const u64 dm = __ballot(dirty);
             if (dm == 0) { verified = 64; break; }
             const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
-            if ((pass >= 2 && fd >= 40) || pass >= MAX_PASSES) { verified = fd; break; }
+            if ((pass >= 2 && fd >= (u32)XFG_ACCEPT_FD) || pass >= MAX_PASSES) { verified = fd; break; }
         }
         PROF_ADD(PF_COUNT, lane);
         const bool live = !dead && lane < verified;              // live lanes are 0 .. nlive-1
@@ -1018,7 +1033,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             PROF_T0();
             if (keep) {
                 if (tail) fin = decode_segment_tail<true>(L, wb0, start, seg_end, total_bits, dist_empty, woff + rel, o.pos + rel, moff, err_out);
-                else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, dist_empty, woff + rel, o.pos + rel, moff, lane, err_out);
+                else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, woff + rel, o.pos + rel, moff, lane, err_out);
             }
             wave_sync();
             PROF_ADD(PF_EMIT, lane);
