@@ -30,6 +30,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 counter passes (profiles/r1/traffic.json), or None.
+    FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes), WRITE_SIZE is exact; both in KB."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))[workload]
+        return int((2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
+
 WORKLOADS = {
     # name: (chunks per GPU, chunk size, kinds, zlib level, distinct chunks generated)
     "c2": (16384, 65536, ("huffman", "repeats", "digits"), 6, 768),
@@ -211,7 +221,7 @@ def main():
                        "raw_bytes_per_gpu": raw_len, "comp_bytes_per_gpu": comp_len,
                        "ratio": round(raw_len / comp_len, 3), "verified_bit_exact": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload),
                          "kernel": "inflate_chunks_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
