@@ -83,7 +83,13 @@ constexpr int NPF = (BWIN_BYTES + 1023) / 1024;     // 16-byte units per lane th
 constexpr int OUT_LDS = XFG_OUT_LDS;    // bytes of batch output staged in LDS
 constexpr int OUT_CAP = OUT_LDS - 258;  // a lane stops at the token that takes it to OUT_CAP: one lane always fits
 constexpr int TOK_MAX = XFG_TOK_MAX;    // match tokens per batch
-constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix
+constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix (careful path)
+#ifndef XFG_MAX_FIX
+#define XFG_MAX_FIX 5
+#endif
+constexpr int MAX_FIX = XFG_MAX_FIX;    // re-synchronisation walks per batch before settling for the stable prefix
+constexpr int MASK_WORDS = (SEG_BITS + 48 + 31) / 32;   // a path ends less than 48 bits after its segment
+static_assert(MASK_WORDS * 64 <= TOK_MAX, "the token-start masks share the token list's LDS");
 static_assert(OUT_CAP >= 1024, "output window too small");
 static_assert(TOK_MAX >= SEG_BITS / 2, "one lane's tokens (>= 2 bits each) must fit the token list");
 static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
@@ -159,7 +165,11 @@ struct alignas(16) WaveLds {
                                     // the flush is 16-byte aligned on both sides (+ 64 bytes that nobody reads)
         HeaderScratch h;
     };
-    u32 tok[TOK_MAX];               // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
+    union {
+        u32 tok[TOK_MAX];           // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
+        u32 mask[MASK_WORDS * 64];  // synchronisation passes only: token-start bits of every lane's speculative path,
+                                    // word w of lane l at [w * 64 + l]
+    };
     u16 tdst[TOK_MAX];              // their destinations in the output window
 #ifdef XFG_PROFILE
     unsigned long long prof[PF_COUNTERS];
@@ -788,6 +798,72 @@ out:
     return r;
 }
 
+// Synchronisation passes: the same walk as decode_segment_fast without the bookkeeping -- only
+// where the tokens start matters.
+//   CHECK = false  the speculative pass.  Lane decodes from its segment boundary and sets a bit in
+//                  its row of L.mask for every position where a token starts (its start included).
+//   CHECK = true   a lane whose true start became known walks from there until it stands on a
+//                  marked position: from that point on it would repeat the speculative path, so
+//                  that path's end is its end (returns merged = true), or until its own end.
+// Returns the bit position after the last token; e_out = the entry that ended the walk.
+template <bool CHECK>
+__device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 seg_start, u32 lane,
+                                            u32 &e_out, bool &merged)
+{
+    const u32 tab0 = (u32)(uintptr_t)(lds_cu32p)L.tab;
+    const u32 tab1 = tab0 + 4u * LIT_TAB;
+    const u32 win0 = (u32)(uintptr_t)(lds_cu8p)reinterpret_cast<const u8 *>(L.win);
+    u32 *mrow = L.mask + lane;
+    u32 wp = win0 + (u32)((i32)(start >> 3) - wb0);
+    u64 nextw;
+    nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
+    u64 buf = nextw >> (start & 7);
+    u32 cnt = 56 - (start & 7);
+    wp += 7;
+    nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
+    u32 rel = start - seg_start;                               // position in the lane's own segment
+    u32 tb = tab0, tw = LIT_ROOT;
+    u32 e = 0, hit = 0;
+    u32 tokprev = ~0u;                                          // the walk starts at a token boundary
+    if (!CHECK) mrow[(rel >> 5) << 6] = 1u << (rel & 31);       // rows were cleared: a plain store
+    for (;;) {
+        buf |= nextw << cnt;
+        wp += (63 - cnt) >> 3;
+        cnt |= 56;
+        nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
+#pragma unroll
+        for (int step = 0; step < 2; step++) {
+            const u32 lo = (u32)buf;
+            e = *(lds_cu32p)(uintptr_t)(tb + (__builtin_amdgcn_ubfe(lo, 0u, tw) << 2));
+            if (CHECK) {
+                const u32 w = mrow[(rel >> 5) << 6];
+                hit = (w >> (rel & 31)) & tokprev & 1u;
+            }
+            const u32 take = e & 31, xb = __builtin_amdgcn_ubfe(e, 5u, 5u), val = e >> 16;
+            const u32 m_len = (u32)__builtin_amdgcn_sbfe((int)e, 11u, 1u);
+            const u32 m_sub = (u32)__builtin_amdgcn_sbfe((int)e, 13u, 1u);
+            const u32 m_tok = (u32)__builtin_amdgcn_sbfe((int)e, 10u, 1u) | (u32)__builtin_amdgcn_sbfe((int)e, 12u, 1u);
+            tb = (m_sub & (val + tab0)) | (~m_sub & ((m_len & tab1) | (~m_len & tab0)));
+            tw = (m_sub & xb) | (~m_sub & ((u32)LIT_ROOT - (m_len & (u32)(LIT_ROOT - DIST_ROOT))));
+            if (CHECK) {
+                if (hit) goto out;                              // nothing of this step counts
+            }
+            buf >>= take; cnt -= take; rel += take;
+            if (!CHECK) {
+                // a token starts at rel (words past the segment exist; nobody tests them)
+                atomicOr(&mrow[(rel >> 5) << 6], m_tok & (1u << (rel & 31)));
+            }
+            tokprev = m_tok;
+            const u32 over = (u32)(SEG_BITS - 1) - rel;         // negative = at or past the segment end
+            if ((i32)((over & m_tok) | e) < 0) goto out;
+        }
+    }
+out:
+    e_out = e;
+    merged = CHECK && hit != 0;
+    return seg_start + rel;
+}
+
 // Inclusive prefix sum over the wave with DPP row shifts and row broadcasts (no LDS traffic).
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);    // row_shr:1
@@ -955,7 +1031,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
     const bool dist_empty = dist_state == 1;
     const i64 stream0 = (i64)(r.base_al + r.lead);              // address of stream byte 0, relative to comp
     uint4 pf[NPF];
-    bool have_pf = false;
+    bool have_pf = false, force_tail = false;
+    u32 want = 64;                                              // lanes worth synchronising: what the last batch could keep, and some
     for (u32 nbatch = 0;; nbatch++) {
         if (nbatch > total_bits + 4) { be.status = XFG_ST_INTERNAL; be.bitpos = p0; return be; }   // every batch consumes >= 1 bit
         // ---- compressed window of this batch (fetched during the previous batch's stage 2 when there was one)
@@ -971,36 +1048,88 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         have_pf = false;
         PROF_CNT(PF_N_BATCH, 1, lane);
         PROF_T0();
-        // wave-uniform: batches that may meet the end of the stream, and blocks without a distance code, go the careful way
-        const bool tail = dist_empty || p0 + 64u * SEG_BITS + 64u > total_bits;
+        // wave-uniform: blocks without a distance code, and batches in which a token ran past the end of
+        // the stream (seen after the fact, below), go the careful way
+        const bool tail = dist_empty || force_tail || p0 + 64u > total_bits;
+        force_tail = false;
 
-        // ---- stage 1a: speculative passes until the chain of segment starts is stable
         u32 start = p0 + lane * SEG_BITS;
+        const u32 seg_start = start;
         const u32 seg_end = p0 + (lane + 1) * SEG_BITS;
         bool dirty = true, dead = false;
         Seg sg;
         sg.end = start; sg.nout = 0; sg.nmatch = 0; sg.flag = F_NONE;
         u32 dummy = 0;
         u32 verified = 64;
-        for (int pass = 1;; pass++) {
-            if (dirty && !dead) {
-                if (tail) sg = decode_segment_tail<false>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
-                else      sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy);
-            }
+        if (!tail) {
+            // ---- stage 1a: find every lane's true start.  One speculative walk per lane from its segment
+            // boundary, then walks from the predecessor's end that stop as soon as they meet the lane's
+            // own speculative path (prefix codes self-synchronise), until the chain of starts is stable.
+#pragma unroll
+            for (int w = 0; w < MASK_WORDS; w++) L.mask[w * 64 + lane] = 0;
+            u32 eA, e1;
+            bool mg;
+            const u32 endA = sync_segment<false>(L, wb0, start, seg_start, lane, eA, mg);
+            const u32 stopA = eA & E_STOP;
+            u32 end = endA, stop = stopA;
             PROF_CNT(PF_N_PASS, 1, lane);
-            const u32 pe = __shfl_up(sg.end, 1);
-            const u32 pfl = __shfl_up(sg.flag, 1);
-            const u32 pd = __shfl_up((u32)dead, 1);
-            u32 ns = p0;
-            bool nd = false;
-            if (lane > 0) { nd = pd != 0 || pfl != F_NONE; ns = pe; }
-            dirty = (nd != dead) || (!nd && ns != start);
-            start = ns; dead = nd;
-            if (dead) { sg.end = 0; sg.nout = 0; sg.nmatch = 0; sg.flag = F_NONE; }
-            const u64 dm = __ballot(dirty);
-            if (dm == 0) { verified = 64; break; }
-            const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
-            if ((pass >= 2 && fd >= (u32)XFG_ACCEPT_FD) || pass >= MAX_PASSES) { verified = fd; break; }
+            for (int pass = 1;; pass++) {
+                const u32 pe = __shfl_up(end, 1);
+                const u32 pst = __shfl_up(stop, 1);
+                const u32 pd = __shfl_up((u32)dead, 1);
+                u32 ns = p0;
+                bool nd = false;
+                if (lane > 0) { nd = pd != 0 || pst != 0; ns = pe; }
+                dirty = (nd != dead) || (!nd && ns != start);
+                start = ns; dead = nd;
+                const u64 dm = __ballot(dirty);
+                if (dm == 0) { verified = 64; break; }
+                const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
+#ifdef XFG_NO_WANT
+                if (pass > MAX_FIX) { verified = fd; break; }
+#else
+                if (pass > MAX_FIX || fd >= want) { verified = fd; break; }
+#endif
+                if (dirty && !dead) {
+                    const u32 en = sync_segment<true>(L, wb0, start, seg_start, lane, e1, mg);
+                    end = mg ? endA : en;
+                    stop = mg ? stopA : (e1 & E_STOP);
+                }
+                PROF_CNT(PF_N_PASS, 1, lane);
+            }
+            wave_sync();                                        // the masks share LDS with the token list
+            // ---- stage 1a': count bytes and matches along the true path
+            if (!dead && lane < verified) sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy);
+            PROF_CNT(PF_N_PASS, 1, lane);
+            // Whatever the walks above concluded, only a chain that closes is kept: every lane must start
+            // where its predecessor's counted path ended (a lane that stopped at the output cap ends early).
+            const u32 pe2 = __shfl_up(sg.end, 1);
+            const u32 pf2 = __shfl_up(sg.flag, 1);
+            const bool okc = !dead && lane < verified && (lane == 0 || (pe2 == start && pf2 == F_NONE));
+            const u64 bad = ~__ballot(okc);
+            verified = bad ? (u32)__ffsll((long long)bad) - 1 : 64u;
+            // a token that runs past the end of the stream: decode this batch again with the end-of-input checks
+            if (__ballot(lane < verified && sg.end > total_bits)) { force_tail = true; have_pf = false; continue; }
+        } else {
+            // ---- stage 1a (careful): speculative passes until the chain of segment starts is stable
+            for (int pass = 1;; pass++) {
+                if (dirty && !dead)
+                    sg = decode_segment_tail<false>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
+                PROF_CNT(PF_N_PASS, 1, lane);
+                const u32 pe = __shfl_up(sg.end, 1);
+                const u32 pfl = __shfl_up(sg.flag, 1);
+                const u32 pd = __shfl_up((u32)dead, 1);
+                u32 ns = p0;
+                bool nd = false;
+                if (lane > 0) { nd = pd != 0 || pfl != F_NONE; ns = pe; }
+                dirty = (nd != dead) || (!nd && ns != start);
+                start = ns; dead = nd;
+                if (dead) { sg.end = 0; sg.nout = 0; sg.nmatch = 0; sg.flag = F_NONE; }
+                const u64 dm = __ballot(dirty);
+                if (dm == 0) { verified = 64; break; }
+                const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
+                if ((pass >= 2 && fd >= (u32)XFG_ACCEPT_FD) || pass >= MAX_PASSES) { verified = fd; break; }
+            }
         }
         PROF_ADD(PF_COUNT, lane);
         const bool live = !dead && lane < verified;              // live lanes are 0 .. nlive-1
@@ -1017,6 +1146,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         const u32 lflag = lane_get(sg.flag, lastl);
         const u32 lend = lane_get(sg.end, lastl);
         PROF_CNT(PF_N_LIVE, nkeep, lane);
+        want = nkeep >= 48 ? 64u : 2 * nkeep + 8;               // output-bound batches keep few lanes: do not chase the rest
 
         // ---- the next batch's compressed window: on its way while this batch is emitted and resolved
         if (lflag == F_NONE && lend > p0) {
@@ -1221,7 +1351,16 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
     }
 }
 
-// Persistent grid: wave w of the grid takes chunks w, w + W, w + 2W, ...
+// The next chunk of the table for this wave: one atomic per wave, the value broadcast to all lanes.
+// Kept out of line so that the chunk loop below stays a plain loop with a wave-uniform trip count.
+__device__ __attribute__((noinline)) u32 draw_chunk(u32 *counter)
+{
+    u32 v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(counter, 1u);
+    return uni(v);
+}
+
+// Persistent grid: every wave draws chunks from a shared counter until the table is exhausted.
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
 inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
                       u8 *__restrict__ raw, xfg_result *__restrict__ res,
@@ -1234,11 +1373,22 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
 #ifdef XFG_PROFILE
     if (lane < PF_COUNTERS) L.prof[lane] = 0;
 #endif
+    // Dynamic schedule: every wave of the persistent grid takes the next chunk of the table from a
+    // counter in scratch[0] (zeroed by the host before each launch).  Chunks differ a lot in cost
+    // (stored vs Huffman-heavy), so a static stride leaves waves idle at the end.  The trip count
+    // is wave-uniform: lane 0 draws, everybody reads its value.
+#ifndef XFG_STATIC_SCHED
+    u32 ci = draw_chunk(scratch);
+    while (ci < n) {
+        inflate_chunk(comp, chunks, ci, raw, res, L, lane);
+        ci = draw_chunk(scratch);
+    }
+#else
     (void)scratch;
-    // Static round-robin over the persistent grid: the trip count is provably wave-uniform.
     const u32 stride = gridDim.x * WAVES_PER_BLOCK;
     for (u32 ci = blockIdx.x * WAVES_PER_BLOCK + wave; ci < n; ci += stride)
         inflate_chunk(comp, chunks, ci, raw, res, L, lane);
+#endif
 }
 
 } // namespace xfg
@@ -1289,6 +1439,8 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunk
 {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = xfg_grid_blocks(n, num_cu);
+    hipError_t e = hipMemsetAsync(d_scratch, 0, 4, stream);      // the chunk counter
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(xfg::inflate_chunks_kernel, dim3(blocks), dim3(64 * xfg::WAVES_PER_BLOCK), 0, stream,
                        (const uint8_t *)d_comp, (const xfg_chunk *)d_chunks, n,
                        (uint8_t *)d_raw, (xfg_result *)d_res, (uint32_t *)d_scratch);
