@@ -51,6 +51,13 @@ WORKLOADS = {
     "digits": (16384, 65536, ("digits",), 6, 256),
     "zeros": (16384, 65536, ("zeros",), 6, 4),
     "random": (16384, 65536, ("random",), 6, 256),
+    # C4: match-copy-bound, 1 MiB chunks written token by token (258-byte matches at 1-32 KiB distances; dist-1 runs)
+    "c4": (1024, 1 << 20, ("match258", "match258", "match258", "run1"), 6, 16),
+    # C5 corners: stored / fixed / dynamic at 16 KiB and 4 MiB chunks
+    "c5_stored_16k": (65536, 16384, ("random",), 0, 256),
+    "c5_stored_4m": (256, 4 << 20, ("random",), 0, 8),
+    "c5_fixed_64k": (16384, 65536, ("text_fixed",), 6, 64),
+    "c5_dynamic_4m": (256, 4 << 20, ("text",), 6, 4),
 }
 
 
@@ -63,7 +70,17 @@ def build_shard(name, rank):
 
     def make(j):
         kind = kinds[j % len(kinds)]
-        raw = synth.GENERATORS[kind](chunk_size, 1 + 1000003 * (j % len(kinds)) + j)
+        seed = 1 + 1000003 * (j % len(kinds)) + j
+        if kind == "match258":
+            return synth.match_chunk(chunk_size, seed)
+        if kind == "run1":
+            return synth.run_chunk(chunk_size, seed & 255)
+        if kind in ("text", "text_fixed"):
+            twain = open(os.path.join(ROOT, "tests", "golden", "twain.txt"), "rb").read()
+            rep = twain * (chunk_size // len(twain) + 2)
+            raw = rep[(seed * 977) % len(twain):][:chunk_size]
+            return raw, synth.deflate_chunk(raw, level, zlib.Z_FIXED if kind == "text_fixed" else zlib.Z_DEFAULT_STRATEGY)
+        raw = synth.GENERATORS[kind](chunk_size, seed)
         return raw, synth.deflate_chunk(raw, level, zlib.Z_DEFAULT_STRATEGY)
 
     with ThreadPoolExecutor(16) as ex:

@@ -56,22 +56,26 @@ typedef int64_t i64;
 
 constexpr int WAVES_PER_BLOCK = 1;
 constexpr int MAX_BLOCKS_PER_CU = 32;    // hardware limit of waves per CU; the real number comes from the occupancy query
-constexpr int LIT_ROOT = 10;            // first-level bits, literal/length table
+#ifndef XFG_LIT_ROOT
+#define XFG_LIT_ROOT 9
+#endif
+constexpr int LIT_ROOT = XFG_LIT_ROOT;  // first-level bits, literal/length table
 constexpr int DIST_ROOT = 8;            // first-level bits, distance table
 constexpr int CLEN_ROOT = 7;            // code-length code: max length 7, never needs sub-tables
-constexpr int LIT_TAB = 1344;           // >= enough(286, 10, 15) = 1334 entries
+static_assert(LIT_ROOT == 9 || LIT_ROOT == 10, "LIT_TAB below knows these two");
+constexpr int LIT_TAB = LIT_ROOT == 10 ? 1344 : 864;   // >= enough(286, 10, 15) = 1334, enough(286, 9, 15) = 852 (zlib's enough.c)
 constexpr int DIST_TAB = 416;           // >= enough(30, 8, 15)  = 402 entries
 constexpr int CLEN_TAB = 128;
 constexpr int WIN_BYTES = 1024;         // header reader's window: two 512-byte halves
 constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_SEG_BITS
-#define XFG_SEG_BITS 256
+#define XFG_SEG_BITS 160
 #endif
 #ifndef XFG_OUT_LDS
-#define XFG_OUT_LDS 8192
+#define XFG_OUT_LDS 4096
 #endif
 #ifndef XFG_TOK_MAX
-#define XFG_TOK_MAX 768
+#define XFG_TOK_MAX 512
 #endif
 #ifndef XFG_ACCEPT_FD
 #define XFG_ACCEPT_FD 40              // after the second pass, settle for a verified prefix of this many lanes
