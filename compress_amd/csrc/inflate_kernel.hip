@@ -91,6 +91,12 @@ constexpr int MAX_PASSES = 6;           // speculative passes before settling fo
 #ifndef XFG_MAX_FIX
 #define XFG_MAX_FIX 5
 #endif
+#ifndef XFG_LONG_MATCH
+#define XFG_LONG_MATCH 64
+#endif
+constexpr int LONG_MATCH = XFG_LONG_MATCH;   // matches this long are copied by the whole wave, one at a time
+constexpr int SERIAL_ENTER = 6;         // a parallel batch that keeps this few lanes switches the block to serial batches
+constexpr int SERIAL_BITS = (2 * TOK_MAX < 64 * SEG_BITS) ? 2 * TOK_MAX : 64 * SEG_BITS;   // a match token is >= 2 bits: the list cannot overflow
 constexpr int MAX_FIX = XFG_MAX_FIX;    // re-synchronisation walks per batch before settling for the stable prefix
 constexpr int MASK_WORDS = (SEG_BITS + 48 + 31) / 32;   // a path ends less than 48 bits after its segment
 static_assert(MASK_WORDS * 64 <= TOK_MAX, "the token-start masks share the token list's LDS");
@@ -939,6 +945,32 @@ __device__ __forceinline__ void copy16_g2l(u8 *dst, const u8 *src, u32 n) {
     }
 }
 
+// One long match, copied by the whole wave: byte j of the match is source byte j mod dist
+// (flate/dict_decoder.go:93-100 in closed form).  The dist source bytes end where the destination
+// starts and are final (window) or lie before the window (HBM/L2), so all reads precede all writes
+// of the same bytes and the 64 lanes need no ordering among themselves.
+__device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 woff, u32 d, u32 len, u32 dist, u32 lane) {
+    const i32 s = (i32)d - (i32)dist;
+    // j mod dist for j < 258 by a 20-bit reciprocal: exact because j * (dist - 1) < 2^20
+    const u32 rcp = dist < len ? ((1u << 20) + dist - 1) / dist : 0;
+    u8 b[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const u32 j = lane + 64u * i;
+        b[i] = 0;
+        if (j < len) {
+            const u32 o = j - ((j * rcp) >> 20) * dist;
+            const i32 p = s + (i32)o;
+            b[i] = p < (i32)woff ? gwin[p] : outw[p];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const u32 j = lane + 64u * i;
+        if (j < len) outw[d + j] = b[i];
+    }
+}
+
 // Stage 2: resolve the M match tokens of one batch inside the LDS output window, round-major.
 //   raw/base   the chunk's output so far: bytes [0, base) are final in HBM
 //   outw       the batch's bytes [base, base + total) live at outw[0, total); literals are in place
@@ -947,7 +979,9 @@ __device__ __forceinline__ void copy16_g2l(u8 *dst, const u8 *src, u32 n) {
 // are final once they lie below the destination of the first unresolved token of the round
 // (all earlier rounds are complete, and every literal is in place), so every pass of the
 // inner loop retires at least that token.  A started copy never waits again: what it reads
-// beyond its foreign source bytes it has written itself.
+// beyond its foreign source bytes it has written itself.  Matches of LONG_MATCH bytes and more
+// are not copied by their lane: when such a token is the first unresolved one, the whole wave
+// copies it (copy_long_match).
 __device__ void resolve_tokens(const u8 *raw, u32 base, u32 woff, WaveLds &L, u32 M, u32 lane) {
     u8 *outw = reinterpret_cast<u8 *>(L.out);
     const u8 *gwin = raw + base - woff;                         // HBM address of window position 0
@@ -962,10 +996,11 @@ __device__ void resolve_tokens(const u8 *raw, u32 base, u32 woff, WaveLds &L, u3
             len = (t & 255) + 3;
             dist = (t >> 8) + 1;
         }
+        const bool is_long = len >= (u32)LONG_MATCH;
         u32 cur = d, rem = len;
         const i32 s = (i32)d - (i32)dist;                       // source start, window position
         // ---- bytes before the window
-        if (have && s < (i32)woff) {
+        if (have && !is_long && s < (i32)woff) {
             u32 g = (u32)((i32)woff - s);
             if (g > rem) g = rem;
             const u8 *src = gwin + s;                           // >= raw: dist <= history was checked by the emitter
@@ -987,7 +1022,13 @@ __device__ void resolve_tokens(const u8 *raw, u32 base, u32 woff, WaveLds &L, u3
             rounds++;
             const u32 first = (u32)__ffsll((long long)pm) - 1;
             const i32 water = (i32)lane_get(d, first);          // everything below is final
-            if (pending && e <= water) {
+            if (lane_get((u32)is_long, first)) {                 // wave-uniform
+                copy_long_match(outw, gwin, woff, (u32)water, lane_get(len, first), lane_get(dist, first), lane);
+                if (lane == first) pending = false;
+                wave_sync();
+                continue;
+            }
+            if (pending && !is_long && e <= water) {
                 while (rem) {
                     u32 n = span < rem ? span : rem;
                     if (n > 16) n = 16;
@@ -1037,6 +1078,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
     uint4 pf[NPF];
     bool have_pf = false, force_tail = false;
     u32 want = 64;                                              // lanes worth synchronising: what the last batch could keep, and some
+    bool serial = false;                                        // output-bound stretch (long matches): lane 0 decodes alone
     for (u32 nbatch = 0;; nbatch++) {
         if (nbatch > total_bits + 4) { be.status = XFG_ST_INTERNAL; be.bitpos = p0; return be; }   // every batch consumes >= 1 bit
         // ---- compressed window of this batch (fetched during the previous batch's stage 2 when there was one)
@@ -1059,13 +1101,25 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
 
         u32 start = p0 + lane * SEG_BITS;
         const u32 seg_start = start;
-        const u32 seg_end = p0 + (lane + 1) * SEG_BITS;
+        u32 seg_end = p0 + (lane + 1) * SEG_BITS;
         bool dirty = true, dead = false;
         Seg sg;
         sg.end = start; sg.nout = 0; sg.nmatch = 0; sg.flag = F_NONE;
         u32 dummy = 0;
         u32 verified = 64;
-        if (!tail) {
+        if (!tail && serial) {
+            // ---- a few tokens fill the whole output window (long matches): speculation would be thrown
+            // away, so lane 0 walks the batch's bits alone until the window is full
+            seg_end = p0 + (u32)SERIAL_BITS;
+            dead = lane != 0;
+            start = p0;
+            if (!dead) sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy);
+            PROF_CNT(PF_N_PASS, 1, lane);
+            verified = 1;
+            const u32 e0 = lane_get(sg.end, 0);
+            if (e0 > total_bits) { force_tail = true; have_pf = false; continue; }
+            if (lane_get(sg.nout, 0) < (u32)OUT_CAP && lane_get(sg.flag, 0) == F_NONE) serial = false;   // the window did not fill: less compressible again
+        } else if (!tail) {
             // ---- stage 1a: find every lane's true start.  One speculative walk per lane from its segment
             // boundary, then walks from the predecessor's end that stop as soon as they meet the lane's
             // own speculative path (prefix codes self-synchronise), until the chain of starts is stable.
@@ -1151,6 +1205,9 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         const u32 lend = lane_get(sg.end, lastl);
         PROF_CNT(PF_N_LIVE, nkeep, lane);
         want = nkeep >= 48 ? 64u : 2 * nkeep + 8;               // output-bound batches keep few lanes: do not chase the rest
+        // the window (or the token list) cut the batch short after very few lanes: long matches
+        if (!tail && nkeep <= (u32)SERIAL_ENTER && lflag == F_NONE &&
+            (nkeep < (u32)__popcll(__ballot(live)) || lane_get(sg.nout, lastl) >= (u32)OUT_CAP)) serial = true;
 
         // ---- the next batch's compressed window: on its way while this batch is emitted and resolved
         if (lflag == F_NONE && lend > p0) {
