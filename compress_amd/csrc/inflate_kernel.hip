@@ -154,7 +154,8 @@ __device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
 // Cycle and event counters per phase, summed over all waves into a small global array
 // that no other code reads.  The production build compiles all of this away.
 enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
-       PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS, PF_COUNTERS = 16 };
+       PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
+       PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_COUNTERS = 24 };
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -265,6 +266,20 @@ __device__ __forceinline__ void win_ensure(Reader &r) {
     const i32 need = (i32)((q + 7) >> 9);
     if (need > r.blk_hi) {
         if (need > r.blk_hi + 1) r.blk_hi = (i32)(q >> 9) - 1;     // jumped (after a stored block)
+        while (r.blk_hi < need) {
+            r.blk_hi++;
+            win_load(r, r.blk_hi);
+        }
+        wave_sync();
+    }
+}
+
+// Make sure the n (<= 512) bytes at stream position bytepos are in the window.
+__device__ __forceinline__ void win_ensure_at(Reader &r, u32 bytepos, u32 n) {
+    const u32 q = bytepos + r.lead;
+    const i32 need = (i32)((q + n - 1) >> 9);
+    if (need > r.blk_hi || (i32)(q >> 9) < r.blk_hi - 1) {
+        if (need > r.blk_hi + 1 || (i32)(q >> 9) < r.blk_hi - 1) r.blk_hi = (i32)(q >> 9) - 1;
         while (r.blk_hi < need) {
             r.blk_hi++;
             win_load(r, r.blk_hi);
@@ -525,46 +540,73 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
         if (lane == 0) L.h.clens[s] = (u8)v;
     }
     wave_sync();
-    const int cst = build_table<T_CLEN, CLEN_ROOT, 0>(L, L.h.clen, L.h.clens, 19, lane);
+    int cst;
+    { PROF_T0(); cst = build_table<T_CLEN, CLEN_ROOT, 0>(L, L.h.clen, L.h.clens, 19, lane); PROF_ADD(PF_H_CLEN, lane); }
     if (cst == 2) return XFG_ST_CORRUPTED;
+    PROF_T0();
 
-    // literal/length and distance code lengths with the 16/17/18 repeaters (prefix.go:125-165)
+    // literal/length and distance code lengths with the 16/17/18 repeaters (prefix.go:125-165).
+    // 64 bit positions at a time: lane i looks up the code word that would start at bit hp + i and
+    // packs what it means; then a wave-uniform walk hops from symbol to symbol through those
+    // answers with readlane (no memory access per symbol).
     const u32 max_syms = hlit + hdist;
+    if (cst == 1) return XFG_ST_CORRUPTED;                      // "decode with empty prefix tree"
+    const u32 total_bits = r.total * 8;
+    u32 hp = reader_bitpos(r);
     u32 prev = 0;                                               // clenLast
-    for (u32 sym = 0; sym < max_syms;) {
-        if (cst == 1) return XFG_ST_CORRUPTED;                  // "decode with empty prefix tree"
-        if (r.bitcnt < 32) refill(r);
-        const u32 e = lookup_clen(L.h.clen, r.bitbuf);
-        if ((i32)e_take(e) > avail(r)) return XFG_ST_UNEXPECTED_EOF;
-        consume(r, e_take(e));
-        if (e & E_STOP) return XFG_ST_CORRUPTED;                // the degenerate filler symbol
-        const u32 c = e_val(e);
-        if (c < 16) {
-            if (lane == 0) L.h.lens[sym] = (u8)c;
-            prev = c;
-            sym++;
-            continue;
+    int st = XFG_ST_OK;
+    for (u32 sym = 0; sym < max_syms && st == XFG_ST_OK;) {
+        win_ensure_at(r, hp >> 3, 16);
+        u32 info;
+        {
+            const u32 qb = hp + lane;
+            const u32 idx = (qb >> 3) + r.lead;                 // window position of the lane's first byte
+            const u32 *w32 = reinterpret_cast<const u32 *>(r.win);
+            const u32 d0 = w32[(idx >> 2) & (WIN_BYTES / 4 - 1)], d1 = w32[((idx >> 2) + 1) & (WIN_BYTES / 4 - 1)];
+            const u32 field = __builtin_amdgcn_alignbyte(d1, d0, idx & 3) >> (qb & 7);    // >= 25 bits; 14 are needed
+            const u32 e = L.h.clen[field & ((1u << CLEN_ROOT) - 1)];
+            const u32 take = e_take(e), c = e_val(e) & 31;
+            const u32 nb = c == 16 ? 2u : c == 17 ? 3u : c == 18 ? 7u : 0u;
+            const u32 xv = (field >> take) & ((1u << nb) - 1);
+            info = take | (nb << 4) | (c << 8) | (xv << 16) | ((e & E_STOP) ? 0x80000000u : 0u);
         }
-        u32 val, rep, nb;
-        if (c == 16) {
-            if (sym == 0) return XFG_ST_CORRUPTED;              // prefix.go:139-141
-            val = prev; nb = 2; rep = 3;
-        } else if (c == 17) { val = 0; nb = 3; rep = 3; }
-        else { val = 0; nb = 7; rep = 11; }
-        if ((i32)nb > avail(r)) return XFG_ST_UNEXPECTED_EOF;
-        rep += peek(r, nb);
-        consume(r, nb);
-        if (c != 16 && rfc_rep16) prev = 0;                     // stdlib: 16 repeats the previous array entry
-        const u32 end = sym + rep;
-        for (u32 k = sym + lane; k < end && k < max_syms; k += 64) L.h.lens[k] = (u8)val;
-        sym = end;
-        if (sym > max_syms) return XFG_ST_CORRUPTED;            // prefix.go:161-163
+        u32 pos = 0;
+        while (pos < 64 && sym < max_syms) {
+            const u32 inf = (u32)__builtin_amdgcn_readlane((int)info, (int)pos);
+            const i32 av = (i32)total_bits - (i32)(hp + pos);
+            const u32 take = inf & 15;
+            if ((i32)take > av) { st = XFG_ST_UNEXPECTED_EOF; break; }
+            pos += take;
+            if (inf >> 31) { st = XFG_ST_CORRUPTED; break; }      // the degenerate filler symbol
+            const u32 c = (inf >> 8) & 31;
+            if (c < 16) {
+                if (lane == 0) L.h.lens[sym] = (u8)c;
+                prev = c;
+                sym++;
+                continue;
+            }
+            if (c == 16 && sym == 0) { st = XFG_ST_CORRUPTED; break; }   // prefix.go:139-141
+            const u32 nb = (inf >> 4) & 7;
+            if ((i32)nb > av - (i32)take) { st = XFG_ST_UNEXPECTED_EOF; break; }
+            pos += nb;
+            const u32 val = c == 16 ? prev : 0u;
+            const u32 rep = (c == 18 ? 11u : 3u) + ((inf >> 16) & 127);
+            if (c != 16 && rfc_rep16) prev = 0;                 // stdlib: 16 repeats the previous array entry
+            const u32 end = sym + rep;
+            for (u32 k = sym + lane; k < end && k < max_syms; k += 64) L.h.lens[k] = (u8)val;
+            sym = end;
+            if (sym > max_syms) { st = XFG_ST_CORRUPTED; break; } // prefix.go:161-163
+        }
+        hp += pos;
     }
+    reader_seek(r, hp);
+    if (st != XFG_ST_OK) return st;
     wave_sync();
+    PROF_ADD(PF_H_LENS, lane);
     // lens[0 .. hlit) literal/length, lens[hlit .. hlit+hdist) distance
-    lit_state = build_table<T_LIT, LIT_ROOT, 0>(L, L.tab, L.h.lens, hlit, lane);
+    { PROF_T0(); lit_state = build_table<T_LIT, LIT_ROOT, 0>(L, L.tab, L.h.lens, hlit, lane); PROF_ADD(PF_H_LIT, lane); }
     if (lit_state == 2) return XFG_ST_CORRUPTED;
-    dist_state = build_table<T_DIST, DIST_ROOT, LIT_TAB>(L, (L.tab + LIT_TAB), L.h.lens + hlit, hdist, lane);
+    { PROF_T0(); dist_state = build_table<T_DIST, DIST_ROOT, LIT_TAB>(L, (L.tab + LIT_TAB), L.h.lens + hlit, hdist, lane); PROF_ADD(PF_H_DIST, lane); }
     if (dist_state == 2) return XFG_ST_CORRUPTED;
     return XFG_ST_OK;
 }

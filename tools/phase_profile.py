@@ -14,7 +14,8 @@ import bench  # noqa: E402
 from compress_amd import capi  # noqa: E402
 
 NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "total",
-         "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens"]
+         "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens",
+         "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table"]
 
 
 def main():
@@ -28,18 +29,21 @@ def main():
         d_raw = torch.zeros(shard["raw_len"] + 64, dtype=torch.uint8, device=dev)
         d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
         L = capi.lib()
-        buf = (ctypes.c_ulonglong * 16)()
+        buf = (ctypes.c_ulonglong * 24)()
         for it in range(2):
-            L.xfg_debug_profile(buf, 16)          # clear
+            L.xfg_debug_profile(buf, 24)          # clear
             ctx.decode_device(d_comp.data_ptr(), len(shard["comp"]), d_chunks.data_ptr(), n,
                               d_raw.data_ptr(), shard["raw_len"], d_res.data_ptr(), None)
             ctx.sync()
-        L.xfg_debug_profile(buf, 16)
+        L.xfg_debug_profile(buf, 24)
         v = {k: buf[i] for i, k in enumerate(NAMES)}
         tot = max(v["total"], 1)
         print("== %s: %d chunks" % (w, n))
         for k in NAMES[:7]:
             print("  %-13s %14d wave-cycles  %5.1f %%" % (k, v[k], 100.0 * v[k] / tot))
+        blk = max(v["n_blocks"], 1)
+        print("  header per block: clen table %.0f, lengths loop %.0f, lit table %.0f, dist table %.0f" %
+              (v["h_clen_table"] / blk, v["h_lens_loop"] / blk, v["h_lit_table"] / blk, v["h_dist_table"] / blk))
         nb = max(v["n_batch"], 1)
         print("  batches %d  passes/batch %.2f  live lanes/batch %.1f  rounds/batch %.1f  blocks %d" %
               (v["n_batch"], v["n_pass"] / nb, v["n_live_lanes"] / nb, v["n_rounds"] / nb, v["n_blocks"]))
