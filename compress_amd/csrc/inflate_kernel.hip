@@ -110,17 +110,19 @@ static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
 //           second-level entries hold what is left of the code word after ROOT bits
 //   [9:5]   number of extra bits (length / distance), or index bits of the second-level table (link)
 //   [15:10] what the step is, one bit each: E_LIT E_LEN E_DIST E_SUB E_STOP (end of block or
-//           invalid code: the lane is finished) E_EOB (with E_STOP: it is the end-of-block symbol)
+//           invalid code: the lane is finished) E_TOK (a token is complete: with E_LIT and E_DIST)
 //   [31:16] literal byte, length base, distance base, code-length symbol, or the second-level
-//           table's BYTE offset in WaveLds::tab; bit 31 is set on E_STOP entries and on no other
+//           table's LDS byte address; on E_STOP entries bit 16 tells the end-of-block symbol from
+//           an invalid code, and bit 31 is set (on no other entry)
 enum : u32 { K_LIT = 0, K_LEN = 1, K_DIST = 2, K_SUB = 3, K_EOB = 4, K_INVALID = 5 };
-enum : u32 { E_LIT = 1u << 10, E_LEN = 1u << 11, E_DIST = 1u << 12, E_SUB = 1u << 13, E_STOP = 1u << 14, E_EOB = 1u << 15,
+enum : u32 { E_LIT = 1u << 10, E_LEN = 1u << 11, E_DIST = 1u << 12, E_SUB = 1u << 13, E_STOP = 1u << 14, E_TOK = 1u << 15,
+             E_EOB = 1u << 16,         // in the value field of an E_STOP entry: it is the end-of-block symbol
              E_SIGN = 1u << 31 };      // set with E_STOP (no other entry's value reaches bit 15): the exit test is a sign test
 enum : int { T_LIT = 0, T_DIST = 1, T_CLEN = 2 };
 
 __device__ __forceinline__ u32 mk_entry(u32 code_bits, u32 kind, u32 extra, u32 val) {
     const u32 take = (kind == K_LEN || kind == K_DIST) ? code_bits + extra : code_bits;
-    const u32 flags = kind == K_LIT ? E_LIT : kind == K_LEN ? E_LEN : kind == K_DIST ? E_DIST :
+    const u32 flags = kind == K_LIT ? (E_LIT | E_TOK) : kind == K_LEN ? E_LEN : kind == K_DIST ? (E_DIST | E_TOK) :
                       kind == K_SUB ? E_SUB : kind == K_EOB ? (E_STOP | E_EOB | E_SIGN) : (E_STOP | E_SIGN);
     return take | (extra << 5) | flags | (val << 16);
 }
@@ -423,6 +425,7 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
     //    sized by the longest code under that prefix (as zlib's inftrees does).
     if (maxlen > (u32)ROOT) {
         u32 next = 1u << ROOT;                                  // running sub-table offset (uniform)
+        const u32 tab_lds = (u32)(uintptr_t)(const __attribute__((address_space(3))) u32 *)L.tab;
         for (u32 ub = end_root; ub < (1u << ROOT); ub += 64) {
             const u32 u = ub + lane;
             const bool act = u < (1u << ROOT);
@@ -447,7 +450,7 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
             const u32 my_off = next + incl - size;
             next += uni(__shfl(incl, 63));
             if (act) {
-                tab[__brev(u) >> (32 - ROOT)] = mk_entry(ROOT, K_SUB, sb, 4 * (my_off + TAB_OFF));   // byte offset in WaveLds::tab
+                tab[__brev(u) >> (32 - ROOT)] = mk_entry(ROOT, K_SUB, sb, tab_lds + 4 * (my_off + TAB_OFF));   // LDS address of the sub-table
                 for (u32 v = 0; v < (1u << sb); v++) {
                     const u32 w = (u << sb) | v;                // (ROOT+sb)-bit code space, MSB-first
                     u32 l = ROOT + 1;
@@ -712,6 +715,7 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
                                                    bool dist_empty, u32 orel, u32 obase, u32 moff, u32 &err_out)
 {
     const u32 *win = reinterpret_cast<const u32 *>(L.win);
+    const u32 tab_lds = (u32)(uintptr_t)(const __attribute__((address_space(3))) u32 *)L.tab;
     u8 *outw = reinterpret_cast<u8 *>(L.out);
     u32 wp = (u32)((i32)(start >> 3) - wb0);
     u64 buf = win_load64(win, wp) >> (start & 7);
@@ -745,7 +749,7 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
         }
         if ((e & E_STOP) || (dist_empty && is_len)) {
             pos += take;
-            flag = (e & E_EOB) ? F_EOB : F_CORRUPT;             // 286/287, 30/31, the degenerate filler, empty distance tree
+            flag = ((e & E_STOP) && (e & E_EOB)) ? F_EOB : F_CORRUPT;   // 286/287, 30/31, the degenerate filler, empty distance tree
             break;
         }
         if (EMIT) {
@@ -758,7 +762,7 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
                 L.tdst[moff + nm] = (u16)(orel + nout);
             }
         }
-        tbase = is_sub ? val : (is_len ? 4u * LIT_TAB : 0u);
+        tbase = is_sub ? val - tab_lds : (is_len ? 4u * LIT_TAB : 0u);
         twidth = is_sub ? xb : (is_len ? (u32)DIST_ROOT : (u32)LIT_ROOT);
         if (is_len) len = value;
         if (is_lit) nout++;
@@ -776,6 +780,8 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
 // arithmetic -- the entry's flag bits become all-ones / all-zero masks that select the next
 // lookup and what to add to the counters -- with one exit test per step and two steps per
 // top-up of the bit buffer.
+// (m & a) | (~m & b) in one v_bitop3
+#define SEL(m, a, b) __builtin_amdgcn_bitop3_b32((m), (a), (b), 0xCA)
 typedef const __attribute__((address_space(3))) u32 *lds_cu32p;
 typedef const __attribute__((address_space(3))) u8 *lds_cu8p;
 struct __attribute__((packed)) PackedU64 { u64 v; };             // 8 bytes at any alignment
@@ -817,6 +823,7 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 star
             const u32 m_len = (u32)__builtin_amdgcn_sbfe((int)e, 11u, 1u);
             const u32 m_dist = (u32)__builtin_amdgcn_sbfe((int)e, 12u, 1u);
             const u32 m_sub = (u32)__builtin_amdgcn_sbfe((int)e, 13u, 1u);
+            const u32 m_tok = (u32)__builtin_amdgcn_sbfe((int)e, 15u, 1u);
             if (EMIT) {
                 // a literal goes to its place; every other step writes a byte nobody reads
                 outw[(m_lit & (orel + nout)) | (~m_lit & ((u32)OUT_LDS + 16 + lane))] = (u8)val;
@@ -828,15 +835,15 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 star
                     L.tdst[moff + nm] = (u16)(orel + nout);
                 }
             }
-            tb = (m_sub & (val + tab0)) | (~m_sub & ((m_len & tab1) | (~m_len & tab0)));
-            tw = (m_sub & xb) | (~m_sub & ((u32)LIT_ROOT - (m_len & (u32)(LIT_ROOT - DIST_ROOT))));
-            len = (value & m_len) | (len & ~m_len);
+            tb = SEL(m_sub, val, SEL(m_len, tab1, tab0));
+            tw = SEL(m_sub, xb, SEL(m_len, (u32)DIST_ROOT, (u32)LIT_ROOT));
+            len = SEL(m_len, value, len);
             nout += (len & m_dist) - m_lit;                     // a literal adds one, a finished match its length
             nm -= m_dist;
             buf >>= take; cnt -= take; rem1 -= take;
             // finished: a token boundary at or past the segment end or the output cap, or an entry that ends the lane
             const u32 over = rem1 | ((u32)(OUT_CAP - 1) - nout);
-            u32 stop = (over & (m_lit | m_dist)) | e;
+            u32 stop = (over & m_tok) | e;
             if (EMIT) stop |= bad;
             if ((i32)stop < 0) goto out;
         }
@@ -894,9 +901,9 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
             const u32 take = e & 31, xb = __builtin_amdgcn_ubfe(e, 5u, 5u), val = e >> 16;
             const u32 m_len = (u32)__builtin_amdgcn_sbfe((int)e, 11u, 1u);
             const u32 m_sub = (u32)__builtin_amdgcn_sbfe((int)e, 13u, 1u);
-            const u32 m_tok = (u32)__builtin_amdgcn_sbfe((int)e, 10u, 1u) | (u32)__builtin_amdgcn_sbfe((int)e, 12u, 1u);
-            tb = (m_sub & (val + tab0)) | (~m_sub & ((m_len & tab1) | (~m_len & tab0)));
-            tw = (m_sub & xb) | (~m_sub & ((u32)LIT_ROOT - (m_len & (u32)(LIT_ROOT - DIST_ROOT))));
+            const u32 m_tok = (u32)__builtin_amdgcn_sbfe((int)e, 15u, 1u);
+            tb = SEL(m_sub, val, SEL(m_len, tab1, tab0));
+            tw = SEL(m_sub, xb, SEL(m_len, (u32)DIST_ROOT, (u32)LIT_ROOT));
             if (CHECK) {
                 if (hit) goto out;                              // nothing of this step counts
             }
