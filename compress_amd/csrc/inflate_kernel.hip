@@ -64,7 +64,7 @@ constexpr int DIST_ROOT = 8;            // first-level bits, distance table
 constexpr int CLEN_ROOT = 7;            // code-length code: max length 7, never needs sub-tables
 static_assert(LIT_ROOT == 9 || LIT_ROOT == 10, "LIT_TAB below knows these two");
 constexpr int LIT_TAB = LIT_ROOT == 10 ? 1344 : 864;   // >= enough(286, 10, 15) = 1334, enough(286, 9, 15) = 852 (zlib's enough.c)
-constexpr int DIST_TAB = 416;           // >= enough(30, 8, 15)  = 402 entries
+constexpr int DIST_TAB = 404;           // >= enough(30, 8, 15)  = 402 entries
 constexpr int CLEN_TAB = 128;
 constexpr int WIN_BYTES = 1024;         // header reader's window: two 512-byte halves
 constexpr int MAX_HIST = 32768;         // flate/common.go:16
@@ -78,7 +78,7 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #define XFG_TOK_MAX 512
 #endif
 #ifndef XFG_ACCEPT_FD
-#define XFG_ACCEPT_FD 40              // after the second pass, settle for a verified prefix of this many lanes
+#define XFG_ACCEPT_FD 56              // settle for a verified prefix of this many lanes (64 = insist on all)
 #endif
 constexpr int SEG_BITS = XFG_SEG_BITS;  // bits of compressed stream per lane and batch
 constexpr int BATCH_BYTES = 64 * SEG_BITS / 8;
@@ -97,6 +97,10 @@ constexpr int MAX_PASSES = 6;           // speculative passes before settling fo
 constexpr int LONG_MATCH = XFG_LONG_MATCH;   // matches this long are copied by the whole wave, one at a time
 constexpr int SERIAL_ENTER = 6;         // a parallel batch that keeps this few lanes switches the block to serial batches
 constexpr int SERIAL_BITS = (2 * TOK_MAX < 64 * SEG_BITS) ? 2 * TOK_MAX : 64 * SEG_BITS;   // a match token is >= 2 bits: the list cannot overflow
+#ifndef XFG_ACCEPT_PASS
+#define XFG_ACCEPT_PASS 2
+#endif
+constexpr int ACCEPT_PASS = XFG_ACCEPT_PASS;   // after this many walks from corrected starts, a chain of XFG_ACCEPT_FD lanes is good enough
 constexpr int MAX_FIX = XFG_MAX_FIX;    // re-synchronisation walks per batch before settling for the stable prefix
 constexpr int MASK_WORDS = (SEG_BITS + 48 + 31) / 32;   // a path ends less than 48 bits after its segment
 static_assert(MASK_WORDS * 64 <= TOK_MAX, "the token-start masks share the token list's LDS");
@@ -157,7 +161,7 @@ __device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
 // that no other code reads.  The production build compiles all of this away.
 enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
        PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
-       PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_COUNTERS = 24 };
+       PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_COUNTERS = 24 };
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -1020,21 +1024,127 @@ __device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 wo
     }
 }
 
-// Stage 2: resolve the M match tokens of one batch inside the LDS output window, round-major.
+// The part of a short match's source that lies before the window (HBM/L2), first 16 bytes at most,
+// as two 8-byte loads that every lane issues whether it has such a token or not: a fixed number of
+// loads per round lets several rounds' loads be in flight before the first store needs them.
+struct PreLoad {
+    u64 a, b;       // n >= 8: bytes [0, 8) and [n - 8, n); n < 8: the bytes are a >> sh
+    u32 tok, dpos;  // the token and where it goes in the window
+    u32 n_sh;       // bytes fetched (0 = nothing to do) | sh << 8
+    u32 g;          // bytes of the match that come from before the window (all of them, not just the first 16)
+};
+__device__ __forceinline__ PreLoad pre_load(const u8 *raw, const u8 *gwin, u32 woff, const WaveLds &L, u32 m, u32 M) {
+    PreLoad p;
+    p.tok = 0; p.dpos = 0; p.n_sh = 0; p.g = 0;
+    const u8 *pa = raw, *pb = raw;                              // a lane without work reads the chunk's first bytes
+    if (m < M) {
+        const u32 t = L.tok[m];
+        const u32 d = L.tdst[m];
+        p.tok = t; p.dpos = d;
+        const u32 len = (t & 255) + 3, dist = (t >> 8) + 1;
+        const i32 s = (i32)d - (i32)dist;
+        if (len < (u32)LONG_MATCH && s < (i32)woff) {
+            u32 g = (u32)((i32)woff - s);
+            if (g > len) g = len;
+            p.g = g;
+            const u32 n = g < 16 ? g : 16;
+            const u8 *src = gwin + s;                           // >= raw: dist <= history was checked by the emitter
+            u32 sh = 0;
+            if (n >= 8) { pa = src; pb = src + n - 8; }
+            else {
+                // 8 bytes that END with the wanted ones (never reading past them), clamped to the chunk's start
+                pa = src + n - 8;
+                if (pa < raw) pa = raw;
+                pb = pa;
+                sh = (u32)(src - pa) * 8;
+            }
+            p.n_sh = n | (sh << 8);
+        }
+    }
+    __builtin_memcpy(&p.a, pa, 8);
+    __builtin_memcpy(&p.b, pb, 8);
+    return p;
+}
+__device__ __forceinline__ void pre_store(u8 *outw, const u8 *gwin, const PreLoad &p) {
+    u8 *dst = outw + p.dpos;
+    const u32 n = p.n_sh & 255, sh = p.n_sh >> 8;
+    if (n >= 8) {
+        lds_store32(dst, (u32)p.a); no_merge();
+        lds_store32(dst + 4, (u32)(p.a >> 32)); no_merge();
+        lds_store32(dst + n - 8, (u32)p.b); no_merge();
+        lds_store32(dst + n - 4, (u32)(p.b >> 32));
+        if (p.g > 16) {                                         // the rest of a longer one, the plain way (rare)
+            const u8 *src = gwin + ((i32)p.dpos - (i32)((p.tok >> 8) + 1));
+            for (u32 off = 16; off < p.g;) {
+                const u32 k = p.g - off < 16 ? p.g - off : 16;
+                copy16_g2l(dst + off, src + off, k);
+                off += k;
+            }
+        }
+    } else if (n >= 4) {
+        const u64 v = p.a >> sh;
+        lds_store32(dst, (u32)v); no_merge();
+        lds_store32(dst + n - 4, (u32)(v >> (8 * (n - 4))));
+    } else if (n) {
+        const u32 v = (u32)(p.a >> sh);
+        const u32 mid = n > 1 ? 1u : 0u;
+        dst[0] = (u8)v; dst[mid] = (u8)(v >> (8 * mid)); dst[n - 1] = (u8)(v >> (8 * (n - 1)));
+    }
+}
+// After its bytes from before the window are in place: does the token still need bytes from inside the
+// window (or is it a long one, which the wave copies whole)?  Those move up to the front of the list.
+__device__ __forceinline__ u32 pre_compact(WaveLds &L, const PreLoad &p, bool have, u32 K, u32 lane) {
+    const u32 len = (p.tok & 255) + 3;
+    const bool need = have && (len >= (u32)LONG_MATCH || p.g < len);
+    const u64 nm = __ballot(need);
+    if (need) {
+        const u32 k = K + (u32)__popcll(nm & ((1ull << lane) - 1));
+        L.tok[k] = p.tok;
+        L.tdst[k] = (u16)p.dpos;
+    }
+    return K + (u32)__popcll(nm);
+}
+
+// Stage 2: resolve the M match tokens of one batch inside the LDS output window.
 //   raw/base   the chunk's output so far: bytes [0, base) are final in HBM
 //   outw       the batch's bytes [base, base + total) live at outw[0, total); literals are in place
-// Round r takes tokens [64r, 64r + 64) of the stream, one per lane.  Source bytes before the
-// window come from HBM/L2 and depend on nothing in the batch.  Source bytes inside the window
+// First sweep, 64 tokens per round and one per lane: source bytes before the window come from
+// HBM/L2 and depend on nothing in the batch; four rounds' loads are in flight together.  Tokens
+// that are complete after that leave the list; the others are compacted to its front (in
+// stream order).  Second sweep over what is left, round-major: source bytes inside the window
 // are final once they lie below the destination of the first unresolved token of the round
-// (all earlier rounds are complete, and every literal is in place), so every pass of the
+// (all earlier tokens are complete, and every literal is in place), so every pass of the
 // inner loop retires at least that token.  A started copy never waits again: what it reads
 // beyond its foreign source bytes it has written itself.  Matches of LONG_MATCH bytes and more
 // are not copied by their lane: when such a token is the first unresolved one, the whole wave
 // copies it (copy_long_match).
-__device__ void resolve_tokens(const u8 *raw, u32 base, u32 woff, WaveLds &L, u32 M, u32 lane) {
+__device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveLds &L, u32 M, u32 lane) {
     u8 *outw = reinterpret_cast<u8 *>(L.out);
     const u8 *gwin = raw + base - woff;                         // HBM address of window position 0
     u32 rounds = 0;
+    const bool swept = cap >= 8;                                // pre_load may read the chunk's first 8 bytes
+    PROF_T0();
+    if (swept) {
+        u32 K = 0;
+        for (u32 r0 = 0; r0 < M; r0 += 256) {
+            const PreLoad p0 = pre_load(raw, gwin, woff, L, r0 + lane, M);
+            const PreLoad p1 = pre_load(raw, gwin, woff, L, r0 + 64 + lane, M);
+            const PreLoad p2 = pre_load(raw, gwin, woff, L, r0 + 128 + lane, M);
+            const PreLoad p3 = pre_load(raw, gwin, woff, L, r0 + 192 + lane, M);
+            wave_sync();                                        // all four rounds' tokens are read before the list is compacted
+            pre_store(outw, gwin, p0);
+            K = pre_compact(L, p0, r0 + lane < M, K, lane);
+            pre_store(outw, gwin, p1);
+            K = pre_compact(L, p1, r0 + 64 + lane < M, K, lane);
+            pre_store(outw, gwin, p2);
+            K = pre_compact(L, p2, r0 + 128 + lane < M, K, lane);
+            pre_store(outw, gwin, p3);
+            K = pre_compact(L, p3, r0 + 192 + lane < M, K, lane);
+        }
+        wave_sync();
+        M = K;
+    }
+    PROF_ADD(PF_R_SWEEP, lane);
     for (u32 r0 = 0; r0 < M; r0 += 64) {
         const u32 m = r0 + lane;
         const bool have = m < M;
@@ -1048,16 +1158,17 @@ __device__ void resolve_tokens(const u8 *raw, u32 base, u32 woff, WaveLds &L, u3
         const bool is_long = len >= (u32)LONG_MATCH;
         u32 cur = d, rem = len;
         const i32 s = (i32)d - (i32)dist;                       // source start, window position
-        // ---- bytes before the window
+        // ---- bytes before the window: in place already, unless the sweep was skipped
         if (have && !is_long && s < (i32)woff) {
             u32 g = (u32)((i32)woff - s);
             if (g > rem) g = rem;
-            const u8 *src = gwin + s;                           // >= raw: dist <= history was checked by the emitter
-            u32 off = 0;
-            while (off < g) {
-                const u32 n = g - off < 16 ? g - off : 16;
-                copy16_g2l(outw + cur + off, src + off, n);
-                off += n;
+            if (!swept) {
+                const u8 *src = gwin + s;                       // >= raw: dist <= history was checked by the emitter
+                for (u32 off = 0; off < g;) {
+                    const u32 n = g - off < 16 ? g - off : 16;
+                    copy16_g2l(outw + cur + off, src + off, n);
+                    off += n;
+                }
             }
             cur += g; rem -= g;
         }
@@ -1192,11 +1303,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 const u64 dm = __ballot(dirty);
                 if (dm == 0) { verified = 64; break; }
                 const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
-#ifdef XFG_NO_WANT
-                if (pass > MAX_FIX) { verified = fd; break; }
-#else
-                if (pass > MAX_FIX || fd >= want) { verified = fd; break; }
-#endif
+                if (pass > MAX_FIX || fd >= want || (pass > ACCEPT_PASS && fd >= (u32)XFG_ACCEPT_FD)) { verified = fd; break; }
                 if (dirty && !dead) {
                     const u32 en = sync_segment<true>(L, wb0, start, seg_start, lane, e1, mg);
                     end = mg ? endA : en;
@@ -1292,7 +1399,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         if (M) {
             PROF_T0();
             mem_sync();                                         // earlier batches' flushed bytes are read back here
-            resolve_tokens(o.raw, o.pos, woff, L, M, lane);
+            PROF_ADD(PF_R_SYNC, lane);
+            resolve_tokens(o.raw, o.cap, o.pos, woff, L, M, lane);
             PROF_ADD(PF_RESOLVE, lane);
         }
         // ---- flush to HBM (never beyond the chunk's capacity)
