@@ -167,11 +167,19 @@ extern "C" int xfg_decode(xfg_ctx *c, const uint8_t *comp, size_t comp_len,
     if (rc != XFG_OK) return rc;
     HIP_TRY(hipMemcpyAsync(res, c->d_res, n * sizeof(xfg_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    // Copy back only what each chunk produced (chunks own disjoint output ranges).
-    for (size_t i = 0; i < n; i++) {
-        const size_t got = (size_t)res[i].out_produced;
-        if (got) HIP_TRY(hipMemcpyAsync(raw + chunks[i].raw_off, (const uint8_t *)c->d_raw + chunks[i].raw_off,
-                                        got, hipMemcpyDeviceToHost, c->stream));
+    // Copy back only what each chunk produced (chunks own disjoint output ranges); chunks whose
+    // outputs follow one another without a gap travel in one copy.
+    for (size_t i = 0; i < n;) {
+        const size_t lo = (size_t)chunks[i].raw_off;
+        size_t hi = lo + (size_t)res[i].out_produced;
+        size_t j = i + 1;
+        while (j < n && (size_t)chunks[j].raw_off == hi &&
+               (size_t)res[j - 1].out_produced == (size_t)chunks[j - 1].raw_size) {
+            hi += (size_t)res[j].out_produced;
+            j++;
+        }
+        if (hi > lo) HIP_TRY(hipMemcpyAsync(raw + lo, (const uint8_t *)c->d_raw + lo, hi - lo, hipMemcpyDeviceToHost, c->stream));
+        i = j;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return XFG_OK;

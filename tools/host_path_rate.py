@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry point xfg_decode (never bench.py's `value`):
+compressed bytes go host -> HBM, the kernel runs, raw bytes and results come back."""
+import ctypes
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from compress_amd import capi  # noqa: E402
+
+bench.WORKLOADS["host"] = (4096, 65536, ("huffman", "repeats", "digits"), 6, 768)
+shard = bench.build_shard("host", 0)
+ctx = capi.Context(0)
+n = shard["n"]
+raw = ctypes.create_string_buffer(shard["raw_len"])
+res = (capi.Result * n)()
+comp = shard["comp"]
+L = capi.lib()
+for it in range(4):
+    t0 = time.perf_counter()
+    rc = L.xfg_decode(ctx._h, comp, len(comp), shard["descs"], n, raw, shard["raw_len"], res)
+    dt = time.perf_counter() - t0
+    assert rc == 0 and all(res[i].status == 0 for i in range(0, n, 97))
+    print("xfg_decode host path: %.1f MiB raw in %.2f ms = %.2f GB/s decompressed" % (shard["raw_len"] / 2**20, dt * 1e3, shard["raw_len"] / dt / 1e9))
+ctx.close()
