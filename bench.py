@@ -143,12 +143,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # Rehearsal on a box with fewer GPUs than ranks (never a bench line): BENCH_ONE_DEVICE=1 puts every
+    # rank on device 0 and rendezvous goes over gloo, since RCCL refuses two ranks on one device.
+    rehearsal = os.environ.get("BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     shard = build_shard(args.workload, rank)
     n = shard["n"]
@@ -208,7 +216,7 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / max(args.steps, 1)
 
     if dist is not None:
-        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
 
@@ -231,7 +239,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic (%d distinct chunks per kind-mix tiled to %d chunks per GPU; seeds in compress_amd/synth.py)" % (nd, n_chunks),
+            "data": ("REHEARSAL, all ranks on one device; " if rehearsal else "") + "synthetic (%d distinct chunks per kind-mix tiled to %d chunks per GPU; seeds in compress_amd/synth.py)" % (nd, n_chunks),
             "config": {"workload": "%s: %d x %d KiB chunks per GPU (%s), zlib level %d, sync flush per chunk; "
                                    "index-range sharded over %d GPU(s)" % (args.workload, n_chunks, chunk_size >> 10,
                                                                           "/".join(kinds), level, world),
@@ -242,7 +250,7 @@ def main():
                          "kernel": "inflate_chunks_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                  # the CPU leg runs at N=1 only
             import oracle
             oracle.build()
             threads = min(16, os.cpu_count() or 1)
