@@ -333,3 +333,58 @@ def test_corrupted_chunks_match_oracle(ctx, orc):
         assert out.raw[c[2]:c[2] + o_on] == o_out
         if st != orc.OUT_FULL:
             assert r.in_consumed == o_in
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_damaged_chunks_fuzz(ctx, orc, seed):
+    """A wider sweep of damage than test_corrupted_chunks_match_oracle: every block type (stored, fixed,
+    dynamic, token-written match chunks), bit flips, byte splices, truncations and garbage tails, with
+    and without the appended endBlock.  Status, offsets and the bytes before the error must equal the oracle's."""
+    from compress_amd import synth, capi
+    rng = random.Random(seed)
+    sources = [
+        synth.deflate_chunk(synth.gen_huffman(30000, seed), 6),
+        synth.deflate_chunk(synth.gen_repeats(30000, seed + 1), 9),
+        synth.deflate_chunk(synth.gen_digits(30000, seed + 2), 1),
+        synth.deflate_chunk(synth.gen_digits(9000, seed + 3), 6, zlib.Z_FIXED),
+        synth.deflate_chunk(synth.gen_random(20000, seed + 4), 0),
+        synth.match_chunk(40000, seed + 5)[1],
+        synth.run_chunk(33000, 7, False)[1],
+        synth.deflate_chunk(synth.gen_huffman(700, seed + 6), 6),
+    ]
+    comp = bytearray()
+    chunks = []
+    cap = 48000
+    for t in range(400):
+        c = bytearray(sources[t % len(sources)])
+        mode = rng.randrange(6)
+        if mode == 0:
+            c[rng.randrange(len(c))] ^= 1 << rng.randrange(8)
+        elif mode == 1:
+            c = c[:rng.randrange(1, len(c))]
+        elif mode == 2:
+            for _ in range(rng.randrange(1, 6)):
+                c[rng.randrange(len(c))] = rng.randrange(256)
+        elif mode == 3:
+            p = rng.randrange(len(c))
+            c[p:p + rng.randrange(1, 40)] = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 40)))
+        elif mode == 4:
+            c = c[:rng.randrange(1, min(len(c), 400))]          # damage inside the first block header
+            c[rng.randrange(len(c))] ^= 0xff
+        else:
+            c += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 30)))
+        flags = rng.choice([0, capi.CHUNK_END_BLOCK, capi.CHUNK_END_BLOCK | capi.CHUNK_RFC_REP16, capi.CHUNK_RFC_REP16])
+        chunks.append((len(comp), len(c), t * cap, cap, flags))
+        comp += c
+        comp += bytes(rng.randrange(0, 4))
+    out, res = ctx.decode(bytes(comp), chunks, cap * len(chunks))
+    for c, r in zip(chunks, res):
+        data = bytes(comp[c[0]:c[0] + c[1]]) + (b"\x01\x00\x00\xff\xff" if c[4] & capi.CHUNK_END_BLOCK else b"")
+        st, o_out, o_in, o_on = orc.inflate(data, cap, rfc_rep16=bool(c[4] & capi.CHUNK_RFC_REP16))
+        want = {orc.OK: capi.ST_OK, orc.CORRUPTED: capi.ST_CORRUPTED, orc.UNEXPECTED_EOF: capi.ST_UNEXPECTED_EOF,
+                orc.OUT_FULL: capi.ST_OUT_FULL}[st]
+        assert r.status == want, (capi.ST_NAMES[r.status], capi.ST_NAMES[want], c)
+        assert r.out_produced == o_on, c
+        assert out.raw[c[2]:c[2] + o_on] == o_out, c
+        if st != orc.OUT_FULL:
+            assert r.in_consumed == o_in, c
