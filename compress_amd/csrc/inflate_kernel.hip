@@ -556,10 +556,11 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
     // 64 bit positions at a time: lane i looks up the code word that would start at bit hp + i and
     // packs what it means; then a wave-uniform walk hops from symbol to symbol through those
     // answers with readlane (no memory access per symbol).
-    const u32 max_syms = hlit + hdist;
+    // (uni(): the walk below must compile to scalar code, so everything it depends on is pinned to SGPRs)
+    const u32 max_syms = uni(hlit + hdist);
     if (cst == 1) return XFG_ST_CORRUPTED;                      // "decode with empty prefix tree"
-    const u32 total_bits = r.total * 8;
-    u32 hp = reader_bitpos(r);
+    const u32 total_bits = uni(r.total * 8);
+    u32 hp = uni(reader_bitpos(r));
     u32 prev = 0;                                               // clenLast
     int st = XFG_ST_OK;
     for (u32 sym = 0; sym < max_syms && st == XFG_ST_OK;) {
