@@ -1025,6 +1025,38 @@ __device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 wo
     }
 }
 
+// Long matches whose whole source lies before the window and does not overlap the destination
+// depend on nothing in the batch: up to four of them are fetched together (one dword per lane
+// and match, plus the last len mod 4 bytes), so their HBM/L2 latencies overlap.
+//   mask  lanes of this round that hold such a token; d/len/dist are the lanes' tokens
+__device__ __forceinline__ void copy_independent_long(u8 *outw, const u8 *gwin, u64 mask, u32 d, u32 len, u32 dist, u32 lane) {
+    while (mask) {
+        u32 dd[4], ll[4], w[4], t[4];
+        const u8 *src[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ll[k] = 0; dd[k] = 0; src[k] = gwin; w[k] = 0; t[k] = 0;
+            if (mask) {
+                const u32 l = (u32)__ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                dd[k] = lane_get(d, l);
+                ll[k] = lane_get(len, l);
+                src[k] = gwin + ((i32)dd[k] - (i32)lane_get(dist, l));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (4 * lane + 4 <= ll[k]) __builtin_memcpy(&w[k], src[k] + 4 * lane, 4);
+            if (lane < (ll[k] & 3)) t[k] = src[k][(ll[k] & ~3u) + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (4 * lane + 4 <= ll[k]) lds_store32(outw + dd[k] + 4 * lane, w[k]);
+            if (lane < (ll[k] & 3)) outw[dd[k] + (ll[k] & ~3u) + lane] = (u8)t[k];
+        }
+    }
+}
+
 // The part of a short match's source that lies before the window (HBM/L2), first 16 bytes at most,
 // as two 8-byte loads that every lane issues whether it has such a token or not: a fixed number of
 // loads per round lets several rounds' loads be in flight before the first store needs them.
@@ -1173,9 +1205,18 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
             }
             cur += g; rem -= g;
         }
+        // ---- long matches that depend on nothing in the batch, four at a time
+        const bool indep = have && is_long && dist >= len && s + (i32)len <= (i32)woff;
+        {
+            const u64 im = __ballot(indep);
+            if (im) {
+                copy_independent_long(outw, gwin, im, d, len, dist, lane);
+                wave_sync();
+            }
+        }
         // ---- bytes inside the window
         const i32 e = s + (i32)(len < dist ? len : dist);       // end of the source bytes other tokens may own
-        bool pending = rem > 0;
+        bool pending = rem > 0 && !indep;
         u32 span = dist;
         for (;;) {
             const u64 pm = __ballot(pending);
@@ -1260,6 +1301,9 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         const bool tail = dist_empty || force_tail || p0 + 64u > total_bits;
         force_tail = false;
 
+        const u32 woff = (u32)((uintptr_t)(o.raw + o.pos) & 15);  // window position of the batch's first byte
+        u32 err_out = 0;
+        bool emitted = false;
         u32 start = p0 + lane * SEG_BITS;
         const u32 seg_start = start;
         u32 seg_end = p0 + (lane + 1) * SEG_BITS;
@@ -1274,7 +1318,10 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             seg_end = p0 + (u32)SERIAL_BITS;
             dead = lane != 0;
             start = p0;
-            if (!dead) sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy);
+            // (alone, its offsets are known: this walk is the emit pass already)
+            if (!dead) sg = decode_segment_fast<true>(L, wb0, start, seg_end, woff, o.pos, 0, lane, err_out);
+            emitted = true;
+            wave_sync();
             PROF_CNT(PF_N_PASS, 1, lane);
             verified = 1;
             const u32 e0 = lane_get(sg.end, 0);
@@ -1374,12 +1421,10 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         }
 
         // ---- stage 1b: final pass, literals into the output window, matches to the token list
-        const u32 woff = (u32)((uintptr_t)(o.raw + o.pos) & 15);  // window position of the batch's first byte
-        u32 err_out = 0;
         Seg fin = sg;
         {
             PROF_T0();
-            if (keep) {
+            if (keep && !emitted) {
                 if (tail) fin = decode_segment_tail<true>(L, wb0, start, seg_end, total_bits, dist_empty, woff + rel, o.pos + rel, moff, err_out);
                 else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, woff + rel, o.pos + rel, moff, lane, err_out);
             }
@@ -1596,18 +1641,11 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
     // counter in scratch[0] (zeroed by the host before each launch).  Chunks differ a lot in cost
     // (stored vs Huffman-heavy), so a static stride leaves waves idle at the end.  The trip count
     // is wave-uniform: lane 0 draws, everybody reads its value.
-#ifndef XFG_STATIC_SCHED
     u32 ci = draw_chunk(scratch);
     while (ci < n) {
         inflate_chunk(comp, chunks, ci, raw, res, L, lane);
         ci = draw_chunk(scratch);
     }
-#else
-    (void)scratch;
-    const u32 stride = gridDim.x * WAVES_PER_BLOCK;
-    for (u32 ci = blockIdx.x * WAVES_PER_BLOCK + wave; ci < n; ci += stride)
-        inflate_chunk(comp, chunks, ci, raw, res, L, lane);
-#endif
 }
 
 } // namespace xfg
