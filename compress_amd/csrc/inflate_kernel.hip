@@ -1005,8 +1005,32 @@ __device__ __forceinline__ void copy16_g2l(u8 *dst, const u8 *src, u32 n) {
 // of the same bytes and the 64 lanes need no ordering among themselves.
 __device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 woff, u32 d, u32 len, u32 dist, u32 lane) {
     const i32 s = (i32)d - (i32)dist;
+    if (dist >= len || dist == 1) {                             // wave-uniform
+        // No wrap inside the match (or one byte repeated): a dword per lane, then the last len mod 4 bytes.
+        const u32 nw = len >> 2, nt = len & 3;
+        const bool rep1 = dist == 1;
+        const i32 p = rep1 ? s : s + (i32)(4 * lane);           // this lane's source dword, window position
+        const i32 q = rep1 ? s : s + (i32)((len & ~3u) + lane); // and its tail byte
+        u32 w = 0, t = 0;
+        if (lane < nw || rep1) {
+            if (rep1) w = (p < (i32)woff ? gwin[p] : outw[p]) * 0x01010101u;
+            else if (p + 4 <= (i32)woff) __builtin_memcpy(&w, gwin + p, 4);
+            else if (p >= (i32)woff) w = lds_load32(outw + p);
+            else {
+                for (int k = 0; k < 4; k++) {
+                    const i32 pk = p + k;
+                    w |= (u32)(pk < (i32)woff ? gwin[pk] : outw[pk]) << (8 * k);
+                }
+            }
+        }
+        if (rep1) t = w;
+        else if (lane < nt) t = q < (i32)woff ? gwin[q] : outw[q];
+        if (lane < nw) lds_store32(outw + d + 4 * lane, w);
+        if (lane < nt) outw[d + (len & ~3u) + lane] = (u8)t;
+        return;
+    }
     // j mod dist for j < 258 by a 20-bit reciprocal: exact because j * (dist - 1) < 2^20
-    const u32 rcp = dist < len ? ((1u << 20) + dist - 1) / dist : 0;
+    const u32 rcp = ((1u << 20) + dist - 1) / dist;
     u8 b[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
