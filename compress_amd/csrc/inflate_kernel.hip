@@ -518,6 +518,8 @@ __device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32
     o.pos += n;
 }
 
+__device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 &total);
+
 // ReadPrefixCodes (flate/prefix.go:83-194).  Returns an XFG_ST_* status.
 __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep16, int &lit_state, int &dist_state) {
     refill(r);
@@ -556,6 +558,7 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
     // 64 bit positions at a time: lane i looks up the code word that would start at bit hp + i and
     // packs what it means; then a wave-uniform walk hops from symbol to symbol through those
     // answers with readlane (no memory access per symbol).
+    for (u32 i = lane; i < sizeof(L.h.lens) / 4; i += 64) reinterpret_cast<u32 *>(L.h.lens)[i] = 0;
     // (uni(): the walk below must compile to scalar code, so everything it depends on is pinned to SGPRs)
     const u32 max_syms = uni(hlit + hdist);
     if (cst == 1) return XFG_ST_CORRUPTED;                      // "decode with empty prefix tree"
@@ -579,31 +582,81 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
             info = take | (nb << 4) | (c << 8) | (xv << 16) | ((e & E_STOP) ? 0x80000000u : 0u);
         }
         u32 pos = 0;
-        while (pos < 64 && sym < max_syms) {
-            const u32 inf = (u32)__builtin_amdgcn_readlane((int)info, (int)pos);
-            const i32 av = (i32)total_bits - (i32)(hp + pos);
-            const u32 take = inf & 15;
-            if ((i32)take > av) { st = XFG_ST_UNEXPECTED_EOF; break; }
-            pos += take;
-            if (inf >> 31) { st = XFG_ST_CORRUPTED; break; }      // the degenerate filler symbol
-            const u32 c = (inf >> 8) & 31;
-            if (c < 16) {
-                if (lane == 0) L.h.lens[sym] = (u8)c;
-                prev = c;
-                sym++;
-                continue;
+        // Fast way: every symbol of the window is whole (no end of input near) -- hop through the window
+        // keeping only positions and counts, then let the lanes that were hopped on store their lengths
+        // at once.  Zero runs need no store (lens[] was cleared); "repeat previous" runs follow in order.
+        bool fast = hp + 64 + 16 <= total_bits && sym > 0;
+        if (fast) {
+            const u32 c = (info >> 8) & 31;
+            const u32 cnt = c < 16 ? 1u : (c == 18 ? 11u : 3u) + ((info >> 16) & 127);
+            const u32 info2 = ((info & 15) + ((info >> 4) & 7)) | (cnt << 8);
+            u64 vis = 0;
+            u32 s2 = sym;
+            while (pos < 64 && s2 < max_syms) {
+                const u32 i2 = (u32)__builtin_amdgcn_readlane((int)info2, (int)pos);
+                vis |= 1ull << pos;
+                pos += i2 & 31;
+                s2 += i2 >> 8;
             }
-            if (c == 16 && sym == 0) { st = XFG_ST_CORRUPTED; break; }   // prefix.go:139-141
-            const u32 nb = (inf >> 4) & 7;
-            if ((i32)nb > av - (i32)take) { st = XFG_ST_UNEXPECTED_EOF; break; }
-            pos += nb;
-            const u32 val = c == 16 ? prev : 0u;
-            const u32 rep = (c == 18 ? 11u : 3u) + ((inf >> 16) & 127);
-            if (c != 16 && rfc_rep16) prev = 0;                 // stdlib: 16 repeats the previous array entry
-            const u32 end = sym + rep;
-            for (u32 k = sym + lane; k < end && k < max_syms; k += 64) L.h.lens[k] = (u8)val;
-            sym = end;
-            if (sym > max_syms) { st = XFG_ST_CORRUPTED; break; } // prefix.go:161-163
+            if (__ballot((info >> 31) != 0) & vis) { fast = false; pos = 0; }    // an invalid code on the path: the exact way
+            else {
+                const bool my = (vis >> lane) & 1;
+                u32 total;
+                const u32 idx = sym + wave_excl_scan(my ? cnt : 0u, total);
+                if (my && c < 16 && idx < max_syms) L.h.lens[idx] = (u8)c;
+                const u64 m16 = __ballot(my && c == 16);
+                const u64 mexp = __ballot(my && c < 16);             // explicit lengths
+                if (m16) {
+                    wave_sync();
+                    for (u64 m = m16; m; m &= m - 1) {
+                        const u32 l = (u32)__ffsll((long long)m) - 1;
+                        const u32 il = (u32)__builtin_amdgcn_readlane((int)idx, (int)l);
+                        const u32 rp = (u32)__builtin_amdgcn_readlane((int)cnt, (int)l);
+                        u32 v;
+                        if (rfc_rep16) v = uni(L.h.lens[il - 1]);    // the previous array entry (il >= 1: sym > 0)
+                        else {
+                            const u64 before = mexp & ((1ull << l) - 1);
+                            v = before ? (u32)__builtin_amdgcn_readlane((int)c, 63 - __builtin_clzll(before)) : prev;
+                        }
+                        if (lane < rp && il + lane < max_syms) L.h.lens[il + lane] = (u8)v;
+                        wave_sync();
+                    }
+                }
+                if (mexp) prev = (u32)__builtin_amdgcn_readlane((int)c, 63 - __builtin_clzll(mexp));
+                sym = s2;
+                if (sym > max_syms) st = XFG_ST_CORRUPTED;          // prefix.go:161-163
+            }
+        }
+        if (!fast) {
+            // Exact way, symbol by symbol: every read of the reference that can fail is checked where it fails.
+            wave_sync();
+            if (rfc_rep16 && sym > 0) prev = uni(L.h.lens[sym - 1]);
+            while (pos < 64 && sym < max_syms) {
+                const u32 inf = (u32)__builtin_amdgcn_readlane((int)info, (int)pos);
+                const i32 av = (i32)total_bits - (i32)(hp + pos);
+                const u32 take = inf & 15;
+                if ((i32)take > av) { st = XFG_ST_UNEXPECTED_EOF; break; }
+                pos += take;
+                if (inf >> 31) { st = XFG_ST_CORRUPTED; break; }      // the degenerate filler symbol
+                const u32 c = (inf >> 8) & 31;
+                if (c < 16) {
+                    if (lane == 0) L.h.lens[sym] = (u8)c;
+                    prev = c;
+                    sym++;
+                    continue;
+                }
+                if (c == 16 && sym == 0) { st = XFG_ST_CORRUPTED; break; }   // prefix.go:139-141
+                const u32 nb = (inf >> 4) & 7;
+                if ((i32)nb > av - (i32)take) { st = XFG_ST_UNEXPECTED_EOF; break; }
+                pos += nb;
+                const u32 val = c == 16 ? prev : 0u;
+                const u32 rep = (c == 18 ? 11u : 3u) + ((inf >> 16) & 127);
+                if (c != 16 && rfc_rep16) prev = 0;                 // stdlib: 16 repeats the previous array entry
+                const u32 end = sym + rep;
+                for (u32 k = sym + lane; k < end && k < max_syms; k += 64) L.h.lens[k] = (u8)val;
+                sym = end;
+                if (sym > max_syms) { st = XFG_ST_CORRUPTED; break; } // prefix.go:161-163
+            }
         }
         hp += pos;
     }
