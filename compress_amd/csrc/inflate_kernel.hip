@@ -1701,7 +1701,8 @@ __device__ __attribute__((noinline)) u32 draw_chunk(u32 *counter)
     return uni(v);
 }
 
-// Persistent grid: every wave draws chunks from a shared counter until the table is exhausted.
+// Persistent grid: every wave draws chunks from a shared counter until the table is exhausted
+// (n <= 2^30: the counter runs to 3 n).
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
 inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
                       u8 *__restrict__ raw, xfg_result *__restrict__ res,
@@ -1718,10 +1719,16 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
     // counter in scratch[0] (zeroed by the host before each launch).  Chunks differ a lot in cost
     // (stored vs Huffman-heavy), so a static stride leaves waves idle at the end.  The trip count
     // is wave-uniform: lane 0 draws, everybody reads its value.
-    u32 ci = draw_chunk(scratch);
-    while (ci < n) {
-        inflate_chunk(comp, chunks, ci, raw, res, L, lane);
-        ci = draw_chunk(scratch);
+    // The counter runs three times over the table: chunks that compress least (the most bits to
+    // decode per output byte: the expensive ones) are taken in the first round, the cheapest in the
+    // last, so that the grid's last wave finishes on a short chunk.
+    const u32 rounds_n = 3u * n;
+    for (u32 v = draw_chunk(scratch); v < rounds_n; v = draw_chunk(scratch)) {
+        const u32 round = v < n ? 0u : (v < 2u * n ? 1u : 2u);
+        const u32 ci = v - round * n;
+        const u64 cs = uni64(chunks[ci].comp_size), rs = uni64(chunks[ci].raw_size);
+        const u32 cls = cs * 8 >= rs * 5 ? 0u : (cs * 4 >= rs ? 1u : 2u);
+        if (cls == round) inflate_chunk(comp, chunks, ci, raw, res, L, lane);
     }
 }
 

@@ -140,7 +140,7 @@ extern "C" int xfg_decode_device(xfg_ctx *c, const void *d_comp, size_t comp_len
     if (n == 0) return XFG_OK;
     if (!d_comp || !d_chunks || !d_res || (!d_raw && raw_len)) return XFG_E_ARG;
     if (((uintptr_t)d_comp & 15) != 0) return XFG_E_ARG;
-    if (n > 0xffffffffull) return XFG_E_ARG;
+    if (n > (1ull << 30)) return XFG_E_ARG;                    // the kernel counts to 3 n in 32 bits
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     // One launch at a time per context: the match-token scratch is per context.
