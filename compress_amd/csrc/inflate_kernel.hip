@@ -72,10 +72,10 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #define XFG_SEG_BITS 160
 #endif
 #ifndef XFG_OUT_LDS
-#define XFG_OUT_LDS 4096
+#define XFG_OUT_LDS 3584
 #endif
 #ifndef XFG_TOK_MAX
-#define XFG_TOK_MAX 512
+#define XFG_TOK_MAX 640
 #endif
 #ifndef XFG_ACCEPT_FD
 #define XFG_ACCEPT_FD 56              // settle for a verified prefix of this many lanes (64 = insist on all)
