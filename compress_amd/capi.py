@@ -48,6 +48,7 @@ SYMBOLS = [
     "xfg_reader_new", "xfg_reader_reset", "xfg_reader_read", "xfg_reader_seek", "xfg_reader_close",
     "xfg_reader_free", "xfg_reader_num_records", "xfg_reader_get_records", "xfg_reader_bytes_read",
     "xfg_reader_set_window", "xfg_index_parse", "xfg_shard_plan", "xfg_flate_decode",
+    "xfg_crc32_device", "xfg_crc32_combine",
 ]
 
 _lib = None
@@ -149,6 +150,22 @@ class Context:
         """Device-pointer batch decode (async).  Pointers are ints (e.g. torch tensor .data_ptr())."""
         check(lib().xfg_decode_device(self._h, d_comp, comp_len, d_chunks, n, d_raw, raw_len, d_res,
                                       stream or None), "xfg_decode_device")
+
+    def crc32_device(self, d_raw, d_chunks, n, d_res, d_crc, stream=None):
+        """xfg_crc32_device (async): CRC-32 of every chunk's decoded bytes into uint32 d_crc[n]; d_res may be 0."""
+        f = lib().xfg_crc32_device
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                      ctypes.c_void_p, ctypes.c_void_p]
+        check(f(self._h, d_raw, d_chunks, n, d_res or None, d_crc, stream or None), "xfg_crc32_device")
+
+
+def crc32_combine(crc_a, crc_b, len_b):
+    """xfg_crc32_combine: crc32(A || B) from crc32(A), crc32(B), len(B)."""
+    f = lib().xfg_crc32_combine
+    f.restype = ctypes.c_uint32
+    f.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
+    return f(crc_a, crc_b, len_b)
 
 
 def index_parse(stream):

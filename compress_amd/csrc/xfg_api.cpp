@@ -185,6 +185,19 @@ extern "C" int xfg_decode(xfg_ctx *c, const uint8_t *comp, size_t comp_len,
     return XFG_OK;
 }
 
+extern "C" int xfg_crc32_device(xfg_ctx *c, const void *d_raw, const void *d_chunks, size_t n,
+                                const void *d_res, void *d_crc, void *hip_stream)
+{
+    if (!c) return XFG_E_ARG;
+    if (n == 0) return XFG_OK;
+    if (!d_raw || !d_chunks || !d_crc) return XFG_E_ARG;
+    if (n > 0xffffffffull) return XFG_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HIP_TRY(xfg_launch_crc32(d_raw, d_chunks, d_res, (uint32_t)n, d_crc, c->num_cu, s));
+    return XFG_OK;
+}
+
 extern "C" int xfg_flate_decode(xfg_ctx *c, const uint8_t *in, size_t in_len,
                                 uint8_t *out, size_t out_cap,
                                 int64_t *in_off, int64_t *out_off, int *err)

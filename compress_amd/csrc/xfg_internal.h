@@ -9,5 +9,7 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunk
                                          void *d_raw, void *d_res, void *d_scratch,
                                          int num_cu, hipStream_t stream);
 extern "C" size_t xfg_scratch_bytes(int num_cu);
+extern "C" hipError_t xfg_launch_crc32(const void *d_raw, const void *d_chunks, const void *d_res, uint32_t n,
+                                       void *d_crc, int num_cu, hipStream_t stream);
 
 #endif

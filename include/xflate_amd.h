@@ -121,6 +121,18 @@ int xfg_decode(xfg_ctx *ctx, const uint8_t *comp, size_t comp_len,
 int xfg_decode_device(xfg_ctx *ctx, const void *d_comp, size_t comp_len,
                       const void *d_chunks, size_t n,
                       void *d_raw, size_t raw_len, void *d_res, void *hip_stream);
+/*
+ * CRC-32 (IEEE 802.3: Go's hash/crc32.IEEE, the checksum of gzip trailers and of the XFLATE
+ * index, xflate/reader.go:386) of every chunk's decoded bytes, computed where they are: the
+ * reference's gzip embedding hashes on the CPU while writing (xflate/example_test.go:171-182),
+ * a GPU reader checks the trailer with this.  Device pointers, asynchronous like
+ * xfg_decode_device.  d_crc[i] = crc32(raw[raw_off_i .. raw_off_i + out_produced_i)); d_res may
+ * be NULL (then every chunk counts raw_size bytes).
+ */
+int xfg_crc32_device(xfg_ctx *ctx, const void *d_raw, const void *d_chunks, size_t n,
+                     const void *d_res, void *d_crc /* uint32_t[n] */, void *hip_stream);
+/* crc32(A || B) from crc32(A), crc32(B), len(B): folds the per-chunk values into the stream's. Host only. */
+uint32_t xfg_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 /* Wait for everything enqueued on the context's stream. */
 int xfg_sync(xfg_ctx *ctx);
 

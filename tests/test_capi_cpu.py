@@ -66,3 +66,15 @@ def test_index_parse_large_synthetic():
     assert len(chunks) == len(xr.idx.records)
     assert sum(c.raw_size for c in chunks) == len(raw)
     assert chunks[-1].comp_off + chunks[-1].comp_size == len(stream)
+
+
+def test_crc32_combine_matches_zlib():
+    """xfg_crc32_combine (host only) against C zlib: hash/crc32.IEEE is the same polynomial
+    (xflate/reader.go:386, xflate/example_test.go:171)."""
+    import random
+    import zlib
+    rng = random.Random(4)
+    for _ in range(50):
+        a = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 300)))
+        b = bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 2, 255, 256, 1000, 70000])))
+        assert capi.crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
