@@ -161,7 +161,7 @@ __device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
 // that no other code reads.  The production build compiles all of this away.
 enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
        PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
-       PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_COUNTERS = 24 };
+       PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_P_SPEC, PF_P_FIX, PF_P_COUNT, PF_N_FIX, PF_COUNTERS = 24 };
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -996,6 +996,10 @@ __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 &total) {
     total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
     return incl - v;
 }
+// The value of the lane below (lane 0 keeps its own): one DPP move, no LDS crossbar.
+__device__ __forceinline__ u32 lane_prev(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);    // wave_shr:1
+}
 __device__ __forceinline__ u32 lane_get(u32 v, u32 l) {       // l is wave-uniform
     return (u32)__builtin_amdgcn_readlane((int)v, (int)l);
 }
@@ -1412,14 +1416,15 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             for (int w = 0; w < MASK_WORDS; w++) L.mask[w * 64 + lane] = 0;
             u32 eA, e1;
             bool mg;
-            const u32 endA = sync_segment<false>(L, wb0, start, seg_start, lane, eA, mg);
+            u32 endA;
+            { PROF_T0(); endA = sync_segment<false>(L, wb0, start, seg_start, lane, eA, mg); PROF_ADD(PF_P_SPEC, lane); }
             const u32 stopA = eA & E_STOP;
             u32 end = endA, stop = stopA;
             PROF_CNT(PF_N_PASS, 1, lane);
             for (int pass = 1;; pass++) {
-                const u32 pe = __shfl_up(end, 1);
-                const u32 pst = __shfl_up(stop, 1);
-                const u32 pd = __shfl_up((u32)dead, 1);
+                const u32 pe = lane_prev(end);
+                const u32 pst = lane_prev(stop);
+                const u32 pd = lane_prev((u32)dead);
                 u32 ns = p0;
                 bool nd = false;
                 if (lane > 0) { nd = pd != 0 || pst != 0; ns = pe; }
@@ -1429,21 +1434,26 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 if (dm == 0) { verified = 64; break; }
                 const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
                 if (pass > MAX_FIX || fd >= want || (pass > ACCEPT_PASS && fd >= (u32)XFG_ACCEPT_FD)) { verified = fd; break; }
-                if (dirty && !dead) {
-                    const u32 en = sync_segment<true>(L, wb0, start, seg_start, lane, e1, mg);
-                    end = mg ? endA : en;
-                    stop = mg ? stopA : (e1 & E_STOP);
+                {
+                    PROF_T0();
+                    if (dirty && !dead) {
+                        const u32 en = sync_segment<true>(L, wb0, start, seg_start, lane, e1, mg);
+                        end = mg ? endA : en;
+                        stop = mg ? stopA : (e1 & E_STOP);
+                    }
+                    PROF_ADD(PF_P_FIX, lane);
+                    PROF_CNT(PF_N_FIX, 1, lane);
                 }
                 PROF_CNT(PF_N_PASS, 1, lane);
             }
             wave_sync();                                        // the masks share LDS with the token list
             // ---- stage 1a': count bytes and matches along the true path
-            if (!dead && lane < verified) sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy);
+            { PROF_T0(); if (!dead && lane < verified) sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy); PROF_ADD(PF_P_COUNT, lane); }
             PROF_CNT(PF_N_PASS, 1, lane);
             // Whatever the walks above concluded, only a chain that closes is kept: every lane must start
             // where its predecessor's counted path ended (a lane that stopped at the output cap ends early).
-            const u32 pe2 = __shfl_up(sg.end, 1);
-            const u32 pf2 = __shfl_up(sg.flag, 1);
+            const u32 pe2 = lane_prev(sg.end);
+            const u32 pf2 = lane_prev(sg.flag);
             const bool okc = !dead && lane < verified && (lane == 0 || (pe2 == start && pf2 == F_NONE));
             const u64 bad = ~__ballot(okc);
             verified = bad ? (u32)__ffsll((long long)bad) - 1 : 64u;
@@ -1455,9 +1465,9 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 if (dirty && !dead)
                     sg = decode_segment_tail<false>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
                 PROF_CNT(PF_N_PASS, 1, lane);
-                const u32 pe = __shfl_up(sg.end, 1);
-                const u32 pfl = __shfl_up(sg.flag, 1);
-                const u32 pd = __shfl_up((u32)dead, 1);
+                const u32 pe = lane_prev(sg.end);
+                const u32 pfl = lane_prev(sg.flag);
+                const u32 pd = lane_prev((u32)dead);
                 u32 ns = p0;
                 bool nd = false;
                 if (lane > 0) { nd = pd != 0 || pfl != F_NONE; ns = pe; }

@@ -15,7 +15,7 @@ from compress_amd import capi  # noqa: E402
 
 NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "total",
          "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens",
-         "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep"]
+         "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix"]
 
 
 def main():
@@ -45,6 +45,8 @@ def main():
         print("  header per block: clen table %.0f, lengths loop %.0f, lit table %.0f, dist table %.0f" %
               (v["h_clen_table"] / blk, v["h_lens_loop"] / blk, v["h_lit_table"] / blk, v["h_dist_table"] / blk))
         nb = max(v["n_batch"], 1)
+        print("  walks per batch: speculative %.0f, re-synchronisation %.0f (%.2f walks), count %.0f cycles" %
+              (v["p_spec"] / nb, v["p_fix"] / nb, v["n_fix"] / nb, v["p_count"] / nb))
         print("  resolve per batch: wait for earlier stores %.0f, pre-window sweep %.0f" % (v["r_sync"] / nb, v["r_sweep"] / nb))
         print("  batches %d  passes/batch %.2f  live lanes/batch %.1f  rounds/batch %.1f  blocks %d" %
               (v["n_batch"], v["n_pass"] / nb, v["n_live_lanes"] / nb, v["n_rounds"] / nb, v["n_blocks"]))
