@@ -2,28 +2,34 @@
 //
 // One wavefront owns one chunk at a time.  A
 // workgroup is one wave.  The grid is persistent (as many workgroups as fit the
-// CUs' LDS) and walks the chunk table round-robin.
+// CUs' LDS); every wave draws its next chunk from a counter, expensive chunks first.
 //
-// Inside a Huffman block the 64 lanes decode 64 consecutive SEG_BITS-bit segments
+// Inside a Huffman block the 64 lanes work on 64 consecutive SEG_BITS-bit segments
 // of the bit stream at once (decode_huffman_block), one "batch" per iteration:
-//   stage 1  speculative decode: lane i starts at segment boundary i, which is
-//            almost never a code-word boundary; prefix codes self-synchronise, so
-//            its END position is usually right anyway.  Lanes then restart from
-//            their predecessor's end until the chain of starts is stable; the
-//            stable prefix of lanes is exactly the serial decoder's token stream.
-//            Every lane runs one table lookup per loop iteration (literal/length
-//            root, distance root and second-level tables share the instruction:
-//            a small per-lane state machine), from a 64-bit register bit buffer
-//            that is topped up from the LDS copy of the compressed window.
-//            A last pass writes literals to their final positions in an LDS
-//            output window (offsets from a wave prefix sum of bytes per lane)
-//            and appends match tokens to a compact token list in LDS.
-//   stage 2  match resolution, round-major: 64 consecutive tokens per round, one
-//            per lane.  Sources before the window come from HBM/L2 (all lanes'
-//            loads in flight together); sources inside the window are ready once
-//            they lie below the destination of the first unresolved token of the
-//            round.  Overlapping matches double their period per step.  The
-//            window is then flushed to HBM with coalesced 16-byte stores.
+//   stage 1  a. speculative walk: lane i starts at segment boundary i, which is almost
+//               never a code-word boundary, and marks every bit position where one of
+//               its tokens starts (sync_segment<false>).  Prefix codes self-synchronise,
+//               so the tail of its path is usually the true one.
+//            b. re-synchronisation walks: a lane whose true start (its predecessor's
+//               end) differs walks from there until it stands on a marked position --
+//               from then on it would repeat its speculative path (sync_segment<true>)
+//               -- until the chain of starts is stable.
+//            c. count pass along the true path (bytes and matches per lane); wave
+//               prefix sums give output and token offsets.  Only a chain that closes
+//               (every lane starts where its predecessor's counted path ended) is kept.
+//            d. emit pass: literals to their final positions in an LDS output window,
+//               match tokens to a list in LDS.
+//            Every walk is one table lookup per step (literal/length root, distance
+//            root and second-level tables share the instruction stream: a small
+//            per-lane state machine), from a 64-bit register bit buffer that is topped
+//            up from the LDS copy of the compressed window.  Stretches where a few
+//            long matches fill the window are decoded by lane 0 alone (serial batches).
+//   stage 2  match resolution (resolve_tokens): sources before the window come from
+//            HBM/L2, four rounds of 64 tokens in flight; what is left is resolved 64
+//            tokens per round, a source inside the window being ready once it lies
+//            below the destination of the first unresolved token.  Long matches are
+//            copied by the whole wave.  The window is then flushed to HBM with
+//            coalesced 16-byte stores.
 //
 // What this restates, in the reference's terms (all under /root/reference):
 //   chunkReader            xflate/reader.go:32-70      -> win_load(): chunk || 01 00 00 ff ff is a virtual stream
@@ -32,7 +38,7 @@
 //   ReadPrefixCodes        flate/prefix.go:83-194      -> read_dynamic_header()
 //   GeneratePrefixes       internal/prefix/prefix.go:326-384 -> build_table() steps 1-3 (histogram, Kraft, canonical rank)
 //   Decoder.Init           internal/prefix/decoder.go:51-136 -> build_table() steps 4-5 (root table + sub-tables in LDS)
-//   readBlock              flate/reader.go:162-250     -> decode_huffman_block() / decode_segment()
+//   readBlock              flate/reader.go:162-250     -> decode_huffman_block(): sync_segment / decode_segment_fast / _tail
 //   dictDecoder            flate/dict_decoder.go:86-132 -> resolve_tokens(): the output buffer is the window
 //   Read's post-chunk checks xflate/reader.go:186-202  -> epilogue of inflate_chunk()
 //
