@@ -254,11 +254,18 @@ def main():
             import oracle
             oracle.build()
             threads = min(16, os.cpu_count() or 1)
-            dt, bad, _ = cpu_baseline(shard, threads)
-            out["cpu_baseline"] = {"value": round(raw_len / dt / 1e9, 3), "unit": "GB/s", "cores": threads,
+            # about 20 core-seconds of CPU work: the whole shard, several times over; the mean rate is reported
+            reps, total_dt, bad = 0, 0.0, 0
+            while reps < 3 or (total_dt * threads < 20.0 and reps < 64):
+                dt, b, _ = cpu_baseline(shard, threads)
+                total_dt += dt
+                bad += b
+                reps += 1
+            out["cpu_baseline"] = {"value": round(raw_len * reps / total_dt / 1e9, 3), "unit": "GB/s", "cores": threads,
                                    "kind": "port",
-                                   "sample": "this rank's whole shard once (%d chunks, %.2f GiB raw), oracle/inflate_oracle.c "
-                                             "over %d host threads; %d bad chunks" % (n, raw_len / 2**30, threads, bad)}
+                                   "sample": "this rank's whole shard %d times (%d chunks, %.2f GiB raw each), "
+                                             "oracle/inflate_oracle.c over %d host threads, %.1f s wall; %d bad chunks"
+                                             % (reps, n, raw_len / 2**30, threads, total_dt, bad)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
