@@ -388,3 +388,33 @@ def test_damaged_chunks_fuzz(ctx, orc, seed):
         assert out.raw[c[2]:c[2] + o_on] == o_out, c
         if st != orc.OUT_FULL:
             assert r.in_consumed == o_in, c
+
+
+def test_reader_streams_a_large_file(ctx):
+    """xflate.Reader over a 48 MiB stream read front to back in 1 MiB pieces, then a seek into the middle:
+    the read-ahead window grows to large launches and the bytes stay those of the generator."""
+    from compress_amd import xflate, synth, errors
+    stream, _ = synth.build_mix_stream(768, 65536, n_distinct=96)
+    made = [synth.GENERATORS[k](65536, 1 + 1000003 * (i % 3) + i) for i, k in zip(range(96), ["huffman", "repeats", "digits"] * 32)]
+    want = hashlib.sha256()
+    for i in range(768):
+        want.update(made[i % 96])
+    xr, err = xflate.NewReader(io.BytesIO(stream), ctx=ctx)
+    assert err is None
+    got, total = hashlib.sha256(), 0
+    while True:
+        try:
+            b = xr.Read(1 << 20)
+        except errors.EOF:
+            break
+        got.update(b)
+        total += len(b)
+    assert total == 768 * 65536 and got.hexdigest() == want.hexdigest()
+    pos = 300 * 65536 + 12345
+    assert xr.Seek(pos, xflate.SeekStart) == pos
+    b = bytearray()
+    while len(b) < 100000:
+        b += xr.Read(100000 - len(b))
+    ref = b"".join(made[i % 96] for i in range(300, 303))
+    assert bytes(b) == ref[12345:12345 + 100000]
+    xr.Close()
