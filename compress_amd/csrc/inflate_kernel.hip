@@ -83,6 +83,10 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_TOK_MAX
 #define XFG_TOK_MAX 640
 #endif
+#ifndef XFG_SPEC_BACK
+#define XFG_SPEC_BACK 160             // the speculative walk starts this many bits before its segment: by the segment's
+                                      // first bit it has usually met the true path, so the first re-synchronisation walk is one step
+#endif
 #ifndef XFG_ACCEPT_FD
 #define XFG_ACCEPT_FD 56              // settle for a verified prefix of this many lanes (64 = insist on all)
 #endif
@@ -948,7 +952,7 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
     u32 tb = tab0, tw = LIT_ROOT;
     u32 e = 0, hit = 0;
     u32 tokprev = ~0u;                                          // the walk starts at a token boundary
-    if (!CHECK) mrow[(rel >> 5) << 6] = 1u << (rel & 31);       // rows were cleared: a plain store
+    if (!CHECK && (i32)rel >= 0) mrow[(rel >> 5) << 6] = 1u << (rel & 31);   // rows were cleared: a plain store
     for (;;) {
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
@@ -973,8 +977,15 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
             }
             buf >>= take; cnt -= take; rel += take;
             if (!CHECK) {
-                // a token starts at rel (words past the segment exist; nobody tests them)
-                atomicOr(&mrow[(rel >> 5) << 6], m_tok & (1u << (rel & 31)));
+                // a token starts at rel (words past the segment exist; nobody tests them); positions
+                // before the segment (the run-in, rel < 0) are nobody's start and are not marked
+                if (XFG_SPEC_BACK) {
+                    const u32 in_seg = ~(u32)((i32)rel >> 31);
+                    const u32 rc = rel & in_seg;
+                    atomicOr(&mrow[(rc >> 5) << 6], m_tok & in_seg & (1u << (rc & 31)));
+                } else {
+                    atomicOr(&mrow[(rel >> 5) << 6], m_tok & (1u << (rel & 31)));
+                }
             }
             tokprev = m_tok;
             const u32 over = (u32)(SEG_BITS - 1) - rel;         // negative = at or past the segment end
@@ -1423,6 +1434,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             u32 eA, e1;
             bool mg;
             u32 endA;
+            if (XFG_SPEC_BACK) start = seg_start - p0 > (u32)XFG_SPEC_BACK ? seg_start - (u32)XFG_SPEC_BACK : p0;   // the run-in never reaches back beyond p0, a true start
             { PROF_T0(); endA = sync_segment<false>(L, wb0, start, seg_start, lane, eA, mg); PROF_ADD(PF_P_SPEC, lane); }
             const u32 stopA = eA & E_STOP;
             u32 end = endA, stop = stopA;
