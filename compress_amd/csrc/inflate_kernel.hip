@@ -84,8 +84,10 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #define XFG_TOK_MAX 640
 #endif
 #ifndef XFG_SPEC_BACK
-#define XFG_SPEC_BACK 160             // the speculative walk starts this many bits before its segment: by the segment's
-                                      // first bit it has usually met the true path, so the first re-synchronisation walk is one step
+#define XFG_SPEC_BACK 0               // run-in of the speculative walk, bits before its segment, dynamic blocks
+#endif
+#ifndef XFG_SPEC_BACK_FIXED
+#define XFG_SPEC_BACK_FIXED 480       // the same for fixed blocks, whose near-uniform code lengths take long to synchronise
 #endif
 #ifndef XFG_ACCEPT_FD
 #define XFG_ACCEPT_FD 56              // settle for a verified prefix of this many lanes (64 = insist on all)
@@ -113,7 +115,7 @@ constexpr int SERIAL_BITS = (2 * TOK_MAX < 64 * SEG_BITS) ? 2 * TOK_MAX : 64 * S
 constexpr int ACCEPT_PASS = XFG_ACCEPT_PASS;   // after this many walks from corrected starts, a chain of XFG_ACCEPT_FD lanes is good enough
 constexpr int MAX_FIX = XFG_MAX_FIX;    // re-synchronisation walks per batch before settling for the stable prefix
 constexpr int MASK_WORDS = (SEG_BITS + 48 + 31) / 32;   // a path ends less than 48 bits after its segment
-static_assert(MASK_WORDS * 64 <= TOK_MAX, "the token-start masks share the token list's LDS");
+static_assert(MASK_WORDS * 64 * 4 <= OUT_LDS, "the token-start masks share the output window's LDS");
 static_assert(OUT_CAP >= 1024, "output window too small");
 static_assert(TOK_MAX >= SEG_BITS / 2, "one lane's tokens (>= 2 bits each) must fit the token list");
 static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
@@ -191,12 +193,10 @@ struct alignas(16) WaveLds {
         u64 out[OUT_LDS / 8 + 10];  // output of the current batch at [woff, woff + n), woff = its HBM address mod 16, so that
                                     // the flush is 16-byte aligned on both sides (+ 64 bytes that nobody reads)
         HeaderScratch h;
+        u32 mask[MASK_WORDS * 64];  // synchronisation passes only (before anything is emitted): token-start bits of
+                                    // every lane's speculative path, word w of lane l at [w * 64 + l]
     };
-    union {
-        u32 tok[TOK_MAX];           // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
-        u32 mask[MASK_WORDS * 64];  // synchronisation passes only: token-start bits of every lane's speculative path,
-                                    // word w of lane l at [w * 64 + l]
-    };
+    u32 tok[TOK_MAX];               // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
     u16 tdst[TOK_MAX];              // their destinations in the output window
 #ifdef XFG_PROFILE
     unsigned long long prof[PF_COUNTERS];
@@ -933,7 +933,7 @@ out:
 //                  marked position: from that point on it would repeat the speculative path, so
 //                  that path's end is its end (returns merged = true), or until its own end.
 // Returns the bit position after the last token; e_out = the entry that ended the walk.
-template <bool CHECK>
+template <bool CHECK, bool RUNIN>
 __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 seg_start, u32 lane,
                                             u32 &e_out, bool &merged)
 {
@@ -979,7 +979,7 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
             if (!CHECK) {
                 // a token starts at rel (words past the segment exist; nobody tests them); positions
                 // before the segment (the run-in, rel < 0) are nobody's start and are not marked
-                if (XFG_SPEC_BACK) {
+                if (RUNIN) {
                     const u32 in_seg = ~(u32)((i32)rel >> 31);
                     const u32 rc = rel & in_seg;
                     atomicOr(&mrow[(rc >> 5) << 6], m_tok & in_seg & (1u << (rc & 31)));
@@ -1368,7 +1368,7 @@ struct BlockEnd {
 
 // Decode one Huffman block that starts at bit position p0.  Output goes to o.raw at o.pos.
 __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u32 lane, u32 p0,
-                                         int lit_state, int dist_state)
+                                         int lit_state, int dist_state, u32 spec_back)
 {
     BlockEnd be;
     if (lit_state == 1) { be.status = XFG_ST_CORRUPTED; be.bitpos = p0; return be; }   // empty literal tree
@@ -1434,8 +1434,18 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             u32 eA, e1;
             bool mg;
             u32 endA;
-            if (XFG_SPEC_BACK) start = seg_start - p0 > (u32)XFG_SPEC_BACK ? seg_start - (u32)XFG_SPEC_BACK : p0;   // the run-in never reaches back beyond p0, a true start
-            { PROF_T0(); endA = sync_segment<false>(L, wb0, start, seg_start, lane, eA, mg); PROF_ADD(PF_P_SPEC, lane); }
+            {
+                PROF_T0();
+                if (spec_back) {
+                    // the walk starts before its segment: by the segment's first bit it has usually met the true
+                    // path.  The run-in never reaches back beyond p0, a true start.
+                    start = seg_start - p0 > spec_back ? seg_start - spec_back : p0;
+                    endA = sync_segment<false, true>(L, wb0, start, seg_start, lane, eA, mg);
+                } else {
+                    endA = sync_segment<false, false>(L, wb0, start, seg_start, lane, eA, mg);
+                }
+                PROF_ADD(PF_P_SPEC, lane);
+            }
             const u32 stopA = eA & E_STOP;
             u32 end = endA, stop = stopA;
             PROF_CNT(PF_N_PASS, 1, lane);
@@ -1455,7 +1465,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 {
                     PROF_T0();
                     if (dirty && !dead) {
-                        const u32 en = sync_segment<true>(L, wb0, start, seg_start, lane, e1, mg);
+                        const u32 en = sync_segment<true, false>(L, wb0, start, seg_start, lane, e1, mg);
                         end = mg ? endA : en;
                         stop = mg ? stopA : (e1 & E_STOP);
                     }
@@ -1464,7 +1474,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 }
                 PROF_CNT(PF_N_PASS, 1, lane);
             }
-            wave_sync();                                        // the masks share LDS with the token list
+            wave_sync();                                        // the masks share LDS with the output window
             // ---- stage 1a': count bytes and matches along the true path
             { PROF_T0(); if (!dead && lane < verified) sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy); PROF_ADD(PF_P_COUNT, lane); }
             PROF_CNT(PF_N_PASS, 1, lane);
@@ -1672,7 +1682,8 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
                 if (status != XFG_ST_OK) break;
             }
             PROF_CNT(PF_N_BLOCKS, 1, lane);
-            const BlockEnd be = decode_huffman_block(r, o, L, lane, reader_bitpos(r), lit_state, dist_state);
+            const BlockEnd be = decode_huffman_block(r, o, L, lane, reader_bitpos(r), lit_state, dist_state,
+                                                     btype == 1 ? (u32)XFG_SPEC_BACK_FIXED : (u32)XFG_SPEC_BACK);
             wave_sync();
             reader_seek(r, be.bitpos);                          // the window was reused by the block decoder
             status = be.status;
