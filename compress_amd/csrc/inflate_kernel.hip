@@ -89,6 +89,9 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_SPEC_BACK_FIXED
 #define XFG_SPEC_BACK_FIXED 480       // the same for fixed blocks, whose near-uniform code lengths take long to synchronise
 #endif
+#ifndef XFG_SUBBATCH
+#define XFG_SUBBATCH 1                // 1: a batch's live lanes are written out in as many window-fulls as it takes
+#endif
 #ifndef XFG_ACCEPT_FD
 #define XFG_ACCEPT_FD 56              // settle for a verified prefix of this many lanes (64 = insist on all)
 #endif
@@ -1511,84 +1514,108 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         PROF_ADD(PF_COUNT, lane);
         const bool live = !dead && lane < verified;              // live lanes are 0 .. nlive-1
 
-        // ---- output and token offsets; keep the prefix of lanes that fits the output window and the token list
+        // ---- output and token offsets.  The live lanes are emitted, resolved and flushed one window-full at a
+        // time: each round takes the longest run of lanes, from the first one not yet written, that fits the
+        // output window and the token list.  The walks above are done once for all of them.
         u32 tot_o, tot_m;
-        const u32 rel = wave_excl_scan(live ? sg.nout : 0, tot_o);
-        const u32 moff = wave_excl_scan(live ? sg.nmatch : 0, tot_m);
-        const bool keep = live && rel + sg.nout <= (u32)OUT_LDS && moff + sg.nmatch <= (u32)TOK_MAX;
-        const u32 nkeep = (u32)__popcll(__ballot(keep));        // >= 1: lane 0 is live and one lane always fits
-        const u32 lastl = nkeep - 1;
-        u32 total_out = lane_get(rel + sg.nout, lastl);
-        u32 M = lane_get(moff + sg.nmatch, lastl);
-        const u32 lflag = lane_get(sg.flag, lastl);
-        const u32 lend = lane_get(sg.end, lastl);
-        PROF_CNT(PF_N_LIVE, nkeep, lane);
-        want = nkeep >= 48 ? 64u : 2 * nkeep + 8;               // output-bound batches keep few lanes: do not chase the rest
-        // the window (or the token list) cut the batch short after very few lanes: long matches
-        if (!tail && nkeep <= (u32)SERIAL_ENTER && lflag == F_NONE &&
-            (nkeep < (u32)__popcll(__ballot(live)) || lane_get(sg.nout, lastl) >= (u32)OUT_CAP)) serial = true;
-
-        // ---- the next batch's compressed window: on its way while this batch is emitted and resolved
-        if (lflag == F_NONE && lend > p0) {
-            const i32 nwb0 = (i32)(((stream0 + (lend >> 3)) & ~(i64)15) - stream0);
-            fetch_batch_window(r, nwb0, lane, pf);
-            have_pf = true;
-        }
-
-        // ---- stage 1b: final pass, literals into the output window, matches to the token list
-        Seg fin = sg;
-        {
-            PROF_T0();
-            if (keep && !emitted) {
-                if (tail) fin = decode_segment_tail<true>(L, wb0, start, seg_end, total_bits, dist_empty, woff + rel, o.pos + rel, moff, err_out);
-                else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, woff + rel, o.pos + rel, moff, lane, err_out);
+        const u32 rel0 = wave_excl_scan(live ? sg.nout : 0, tot_o);
+        const u32 moff0 = wave_excl_scan(live ? sg.nmatch : 0, tot_m);
+        const u32 nlive = (u32)__popcll(__ballot(live));        // >= 1: lane 0 is live
+        u32 lflag = F_NONE, lend = p0;
+        for (u32 b0 = 0;;) {
+            const u32 rel = rel0 - lane_get(rel0, b0), moff = moff0 - lane_get(moff0, b0);   // (wraps below b0: those lanes are not kept)
+            const bool keep = live && lane >= b0 && rel + sg.nout <= (u32)OUT_LDS && moff + sg.nmatch <= (u32)TOK_MAX;
+            u32 nkeep = (u32)__popcll(__ballot(keep));          // >= 1: one lane always fits
+#if !XFG_SUBBATCH
+            const bool final = true;
+#else
+            const bool final = b0 + nkeep == nlive;
+#endif
+            const u32 lastl = b0 + nkeep - 1;
+            u32 total_out = lane_get(rel + sg.nout, lastl);
+            u32 M = lane_get(moff + sg.nmatch, lastl);
+            lflag = lane_get(sg.flag, lastl);
+            lend = lane_get(sg.end, lastl);
+            const u32 wo = (u32)((uintptr_t)(o.raw + o.pos) & 15);    // window position of the round's first byte
+            PROF_CNT(PF_N_LIVE, nkeep, lane);
+            if (b0 == 0) {
+#if XFG_SUBBATCH
+                want = 64;
+                // one lane's tokens fill the window: long matches
+                if (!tail && nlive <= (u32)SERIAL_ENTER && lane_get(sg.flag, nlive - 1) == F_NONE &&
+                    lane_get(sg.nout, nlive - 1) >= (u32)OUT_CAP) serial = true;
+#else
+                want = nkeep >= 48 ? 64u : 2 * nkeep + 8;           // output-bound batches keep few lanes: do not chase the rest
+                // the window (or the token list) cut the batch short after very few lanes: long matches
+                if (!tail && nkeep <= (u32)SERIAL_ENTER && lflag == F_NONE &&
+                    (nkeep < nlive || lane_get(sg.nout, lastl) >= (u32)OUT_CAP)) serial = true;
+#endif
             }
-            wave_sync();
-            PROF_ADD(PF_EMIT, lane);
-        }
 
-        // A distance beyond the history ends the chunk at that token (flate/reader.go:223-225).
-        const u64 em = __ballot(keep && fin.flag == F_DIST);
-        u32 elane = 64;
-        if (em) {
-            elane = (u32)__ffsll((long long)em) - 1;
-            total_out = lane_get(rel + err_out, elane);         // tokens after the error do not exist
-            M = lane_get(moff + fin.nmatch, elane);
-        }
-        PROF_CNT(PF_N_TOKENS, M, lane);
-        // ---- stage 2
-        if (M) {
-            PROF_T0();
-            mem_sync();                                         // earlier batches' flushed bytes are read back here
-            PROF_ADD(PF_R_SYNC, lane);
-            resolve_tokens(o.raw, o.cap, o.pos, woff, L, M, lane);
-            PROF_ADD(PF_RESOLVE, lane);
-        }
-        // ---- flush to HBM (never beyond the chunk's capacity)
-        {
-            PROF_T0();
-            u32 nflush = total_out;
-            if (o.pos >= o.cap) nflush = 0; else if (nflush > o.cap - o.pos) nflush = o.cap - o.pos;
-            wave_sync();
-            flush_output(o.raw, o.pos, reinterpret_cast<const u8 *>(L.out), woff, nflush, lane);
-            wave_sync();
-            PROF_ADD(PF_FLUSH, lane);
-        }
+            // ---- the next batch's compressed window: on its way while the last round is emitted and resolved
+            if (final && lflag == F_NONE && lend > p0) {
+                const i32 nwb0 = (i32)(((stream0 + (lend >> 3)) & ~(i64)15) - stream0);
+                fetch_batch_window(r, nwb0, lane, pf);
+                have_pf = true;
+            }
 
-        if (em) {
-            be.status = XFG_ST_CORRUPTED;
-            be.bitpos = lane_get(fin.end, elane);
+            // ---- stage 1b: final pass, literals into the output window, matches to the token list
+            Seg fin = sg;
+            {
+                PROF_T0();
+                if (keep && !emitted) {
+                    if (tail) fin = decode_segment_tail<true>(L, wb0, start, seg_end, total_bits, dist_empty, wo + rel, o.pos + rel, moff, err_out);
+                    else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, wo + rel, o.pos + rel, moff, lane, err_out);
+                }
+                wave_sync();
+                PROF_ADD(PF_EMIT, lane);
+            }
+
+            // A distance beyond the history ends the chunk at that token (flate/reader.go:223-225).
+            const u64 em = __ballot(keep && fin.flag == F_DIST);
+            u32 elane = 64;
+            if (em) {
+                elane = (u32)__ffsll((long long)em) - 1;
+                total_out = lane_get(rel + err_out, elane);     // tokens after the error do not exist
+                M = lane_get(moff + fin.nmatch, elane);
+            }
+            PROF_CNT(PF_N_TOKENS, M, lane);
+            // ---- stage 2
+            if (M) {
+                PROF_T0();
+                mem_sync();                                     // earlier rounds' flushed bytes are read back here
+                PROF_ADD(PF_R_SYNC, lane);
+                resolve_tokens(o.raw, o.cap, o.pos, wo, L, M, lane);
+                PROF_ADD(PF_RESOLVE, lane);
+            }
+            // ---- flush to HBM (never beyond the chunk's capacity)
+            {
+                PROF_T0();
+                u32 nflush = total_out;
+                if (o.pos >= o.cap) nflush = 0; else if (nflush > o.cap - o.pos) nflush = o.cap - o.pos;
+                wave_sync();
+                flush_output(o.raw, o.pos, reinterpret_cast<const u8 *>(L.out), wo, nflush, lane);
+                wave_sync();
+                PROF_ADD(PF_FLUSH, lane);
+            }
+
+            if (em) {
+                be.status = XFG_ST_CORRUPTED;
+                be.bitpos = lane_get(fin.end, elane);
+                o.pos += total_out;
+                if (o.pos > o.cap) { o.pos = o.cap; be.status = XFG_ST_OUT_FULL; }
+                return be;
+            }
+            if (total_out > o.cap - o.pos) {                     // more output than the chunk may hold
+                o.pos = o.cap;
+                be.status = XFG_ST_OUT_FULL;
+                be.bitpos = lend;
+                return be;
+            }
             o.pos += total_out;
-            if (o.pos > o.cap) { o.pos = o.cap; be.status = XFG_ST_OUT_FULL; }
-            return be;
+            if (final) break;
+            b0 += nkeep;
         }
-        if (total_out > o.cap - o.pos) {                         // more output than the chunk may hold
-            o.pos = o.cap;
-            be.status = XFG_ST_OUT_FULL;
-            be.bitpos = lend;
-            return be;
-        }
-        o.pos += total_out;
         if (lflag == F_EOB) { be.status = XFG_ST_OK; be.bitpos = lend; return be; }
         if (lflag == F_CORRUPT) { be.status = XFG_ST_CORRUPTED; be.bitpos = lend; return be; }
         if (lflag == F_EOF) { be.status = XFG_ST_UNEXPECTED_EOF; be.bitpos = lend; return be; }
@@ -1742,7 +1769,10 @@ __device__ __attribute__((noinline)) u32 draw_chunk(u32 *counter)
 
 // Persistent grid: every wave draws chunks from a shared counter until the table is exhausted
 // (n <= 2^30: the counter runs to 3 n).
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
+#ifndef XFG_WAVES_PER_EU
+#define XFG_WAVES_PER_EU 3            // waves per SIMD the register allocation aims at (the LDS footprint must allow as many)
+#endif
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(XFG_WAVES_PER_EU)))
 inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
                       u8 *__restrict__ raw, xfg_result *__restrict__ res,
                       u32 *__restrict__ scratch)
