@@ -78,10 +78,10 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #define XFG_SEG_BITS 160
 #endif
 #ifndef XFG_OUT_LDS
-#define XFG_OUT_LDS 3584
+#define XFG_OUT_LDS 2304
 #endif
 #ifndef XFG_TOK_MAX
-#define XFG_TOK_MAX 640
+#define XFG_TOK_MAX 240
 #endif
 #ifndef XFG_SPEC_BACK
 #define XFG_SPEC_BACK 0               // run-in of the speculative walk, bits before its segment, dynamic blocks
@@ -1770,7 +1770,7 @@ __device__ __attribute__((noinline)) u32 draw_chunk(u32 *counter)
 // Persistent grid: every wave draws chunks from a shared counter until the table is exhausted
 // (n <= 2^30: the counter runs to 3 n).
 #ifndef XFG_WAVES_PER_EU
-#define XFG_WAVES_PER_EU 3            // waves per SIMD the register allocation aims at (the LDS footprint must allow as many)
+#define XFG_WAVES_PER_EU 4            // waves per SIMD the register allocation aims at (the LDS footprint must allow as many)
 #endif
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(XFG_WAVES_PER_EU)))
 inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
