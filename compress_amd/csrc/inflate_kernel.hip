@@ -22,8 +22,9 @@
 //            Every walk is one table lookup per step (literal/length root, distance
 //            root and second-level tables share the instruction stream: a small
 //            per-lane state machine), from a 64-bit register bit buffer that is topped
-//            up from the LDS copy of the compressed window.  Stretches where a few
-//            long matches fill the window are decoded by lane 0 alone (serial batches).
+//            up from the LDS copy of the compressed window.  The verified lanes are then
+//            emitted, resolved and flushed one window-full at a time (rounds).  Stretches
+//            where one lane's tokens fill the window are decoded by lane 0 alone (serial batches).
 //   stage 2  match resolution (resolve_tokens): sources before the window come from
 //            HBM/L2, four rounds of 64 tokens in flight; what is left is resolved 64
 //            tokens per round, a source inside the window being ready once it lies
