@@ -45,6 +45,8 @@ WORKLOADS = {
     "c2": (16384, 65536, ("huffman", "repeats", "digits"), 6, 768),
     "c3": (16384, 262144, ("huffman", "repeats", "digits"), 6, 384),     # 4 GiB per GPU, 256 KiB chunks
     "small": (768, 65536, ("huffman", "repeats", "digits"), 6, 96),
+    "c2x4": (65536, 65536, ("huffman", "repeats", "digits"), 6, 768),    # diagnostic: how much of c2's time is the grid's tail
+
     # single-kind diagnostics (not bench lines): where does the time go per data shape
     "huffman": (16384, 65536, ("huffman",), 6, 256),
     "repeats": (16384, 65536, ("repeats",), 6, 256),

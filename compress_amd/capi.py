@@ -49,6 +49,7 @@ SYMBOLS = [
     "xfg_reader_free", "xfg_reader_num_records", "xfg_reader_get_records", "xfg_reader_bytes_read",
     "xfg_reader_set_window", "xfg_index_parse", "xfg_shard_plan", "xfg_flate_decode",
     "xfg_crc32_device", "xfg_crc32_combine",
+    "xfg_deflate_bound", "xfg_deflate", "xfg_deflate_device",
 ]
 
 _lib = None
@@ -93,6 +94,10 @@ def lib():
     L.xfg_shard_plan.argtypes = [vp, sz, ctypes.c_int, ctypes.POINTER(sz)]
     L.xfg_flate_decode.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(i64), ctypes.POINTER(i64),
                                    ctypes.POINTER(ctypes.c_int)]
+    L.xfg_deflate_bound.argtypes = [sz]
+    L.xfg_deflate_bound.restype = sz
+    L.xfg_deflate.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
+    L.xfg_deflate_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
     _lib = L
     return L
 
@@ -150,6 +155,34 @@ class Context:
         """Device-pointer batch decode (async).  Pointers are ints (e.g. torch tensor .data_ptr())."""
         check(lib().xfg_decode_device(self._h, d_comp, comp_len, d_chunks, n, d_raw, raw_len, d_res,
                                       stream or None), "xfg_decode_device")
+
+    def deflate(self, raw, chunk_size):
+        """xfg_deflate: compress `raw` in chunks of chunk_size bytes (the last one shorter).
+        -> list of compressed chunks, each a DEFLATE stream without a final block ending in 00 00 ff ff."""
+        raw = bytes(raw)
+        sizes = [min(chunk_size, len(raw) - o) for o in range(0, len(raw), chunk_size)] or [0]
+        n = len(sizes)
+        arr = (Chunk * n)()
+        co = ro = 0
+        for i, rs in enumerate(sizes):
+            b = lib().xfg_deflate_bound(rs)
+            arr[i] = Chunk(co, b, ro, rs, 0, 0)
+            co += b
+            ro += rs
+        res = (Result * n)()
+        comp = ctypes.create_string_buffer(max(co, 1))
+        check(lib().xfg_deflate(self._h, raw, len(raw), arr, n, comp, co, res), "xfg_deflate")
+        out = []
+        for i in range(n):
+            if res[i].status != ST_OK:
+                raise TransportError("xfg_deflate: chunk %d status %s" % (i, ST_NAMES[res[i].status]))
+            out.append(comp.raw[arr[i].comp_off:arr[i].comp_off + res[i].out_produced])
+        return out
+
+    def deflate_device(self, d_raw, raw_len, d_chunks, n, d_comp, comp_len, d_res, stream=None):
+        """xfg_deflate_device (async); pointers are ints."""
+        check(lib().xfg_deflate_device(self._h, d_raw, raw_len, d_chunks, n, d_comp, comp_len, d_res,
+                                       stream or None), "xfg_deflate_device")
 
     def crc32_device(self, d_raw, d_chunks, n, d_res, d_crc, stream=None):
         """xfg_crc32_device (async): CRC-32 of every chunk's decoded bytes into uint32 d_crc[n]; d_res may be 0."""

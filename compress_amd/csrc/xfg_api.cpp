@@ -198,6 +198,58 @@ extern "C" int xfg_crc32_device(xfg_ctx *c, const void *d_raw, const void *d_chu
     return XFG_OK;
 }
 
+extern "C" size_t xfg_deflate_bound(size_t raw_size)
+{
+    // the stored coding (5 bytes per 65535, 5 for the sync flush) is the worst case, plus the writer's slack
+    const size_t stored = raw_size + 5 * ((raw_size + 65534) / 65535) + 5;
+    return (stored + 8 + 3) & ~(size_t)3;
+}
+
+extern "C" int xfg_deflate_device(xfg_ctx *c, const void *d_raw, size_t raw_len,
+                                  const void *d_chunks, size_t n,
+                                  void *d_comp, size_t comp_len, void *d_res, void *hip_stream)
+{
+    (void)raw_len; (void)comp_len;
+    if (!c) return XFG_E_ARG;
+    if (n == 0) return XFG_OK;
+    if (!d_chunks || !d_comp || !d_res || (!d_raw && raw_len)) return XFG_E_ARG;
+    if (((uintptr_t)d_comp & 3) != 0 || n > 0xffffffffull) return XFG_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HIP_TRY(xfg_launch_deflate(d_raw, d_chunks, (uint32_t)n, d_comp, d_res, c->num_cu, s));
+    return XFG_OK;
+}
+
+extern "C" int xfg_deflate(xfg_ctx *c, const uint8_t *raw, size_t raw_len,
+                           const xfg_chunk *chunks, size_t n,
+                           uint8_t *comp, size_t comp_len, xfg_result *res)
+{
+    if (!c || (!chunks && n) || (!res && n) || (!raw && raw_len) || (!comp && comp_len)) return XFG_E_ARG;
+    if (n == 0) return XFG_OK;
+    int rc = check_chunks(chunks, n, comp_len, raw_len);        // the same range checks, the other way round
+    if (rc != XFG_OK) return rc;
+    for (size_t i = 0; i < n; i++) if (chunks[i].comp_off & 3) return XFG_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = grow(&c->d_comp, &c->comp_cap, comp_len + 16)) != XFG_OK) return rc;
+    if ((rc = grow(&c->d_raw, &c->raw_cap, raw_len + 16)) != XFG_OK) return rc;
+    if ((rc = grow(&c->d_chunks, &c->chunks_cap, n * sizeof(xfg_chunk))) != XFG_OK) return rc;
+    if ((rc = grow(&c->d_res, &c->res_cap, n * sizeof(xfg_result))) != XFG_OK) return rc;
+    if (raw_len) HIP_TRY(hipMemcpyAsync(c->d_raw, raw, raw_len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_chunks, chunks, n * sizeof(xfg_chunk), hipMemcpyHostToDevice, c->stream));
+    rc = xfg_deflate_device(c, c->d_raw, raw_len, c->d_chunks, n, c->d_comp, comp_len, c->d_res, nullptr);
+    if (rc != XFG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(res, c->d_res, n * sizeof(xfg_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        const size_t k = (size_t)res[i].out_produced;
+        if (res[i].status == XFG_ST_OK && k)
+            HIP_TRY(hipMemcpyAsync(comp + chunks[i].comp_off, (const uint8_t *)c->d_comp + chunks[i].comp_off, k,
+                                   hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return XFG_OK;
+}
+
 extern "C" int xfg_flate_decode(xfg_ctx *c, const uint8_t *in, size_t in_len,
                                 uint8_t *out, size_t out_cap,
                                 int64_t *in_off, int64_t *out_off, int *err)

@@ -137,6 +137,29 @@ uint32_t xfg_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 /* Wait for everything enqueued on the context's stream. */
 int xfg_sync(xfg_ctx *ctx);
 
+/*
+ * Compress n chunks (the write side of the same chunk format).  Replaces
+ * what xflate.Writer does to one chunk: flate.Writer.Write of the chunk's bytes and the sync flush
+ * that ends it (xflate/writer.go:138-165 and 169-204 through xflate/flate.go:97-118), i.e. a DEFLATE
+ * stream without a final block that ends in 00 00 ff ff.  The coding is this library's own (greedy
+ * LZ77, fixed Huffman codes, stored blocks when that is smaller): as with any DEFLATE compressor only
+ * the decoded bytes are pinned, not the compressed ones.  Index and footer stay on the host.
+ *   chunk i reads  raw[raw_off, raw_off + raw_size)
+ *   and writes     comp[comp_off, comp_off + out_produced), out_produced <= comp_size;
+ *   comp_off must be a multiple of 4 and comp_size >= xfg_deflate_bound(raw_size), else the chunk's
+ *   status is XFG_ST_OUT_FULL and nothing is written for it.  flags is ignored, reserved must be 0.
+ *   res[i].in_consumed = raw_size, res[i].out_produced = compressed bytes.
+ * xfg_deflate takes host pointers and blocks; xfg_deflate_device takes device pointers (d_comp at
+ * least 4-byte aligned), enqueues on hip_stream (NULL = the context's stream) and allocates nothing.
+ */
+size_t xfg_deflate_bound(size_t raw_size);
+int xfg_deflate(xfg_ctx *ctx, const uint8_t *raw, size_t raw_len,
+                const xfg_chunk *chunks, size_t n,
+                uint8_t *comp, size_t comp_len, xfg_result *res);
+int xfg_deflate_device(xfg_ctx *ctx, const void *d_raw, size_t raw_len,
+                       const void *d_chunks, size_t n,
+                       void *d_comp, size_t comp_len, void *d_res, void *hip_stream);
+
 /* ======================================================================== */
 /* Host-side mirror of the reference reader                                  */
 /* ======================================================================== */
