@@ -75,14 +75,28 @@ constexpr int DIST_TAB = 404;           // >= enough(30, 8, 15)  = 402 entries
 constexpr int CLEN_TAB = 128;
 constexpr int WIN_BYTES = 1024;         // header reader's window: two 512-byte halves
 constexpr int MAX_HIST = 32768;         // flate/common.go:16
+// Bits of compressed stream per lane and batch: chosen per batch from what the last batch did
+// (seg_bits_for): literal-heavy data wants long segments (a lane's speculative path meets the true
+// one more often before its segment ends: fewer re-synchronisation walks), match-heavy data short
+// ones (a lane's tokens produce many bytes: more lanes fit one window-full).  The LDS windows are
+// sized for the longest; XFG_SEG_BITS != 0 pins one size (tuning runs).
 #ifndef XFG_SEG_BITS
-#define XFG_SEG_BITS 160
+#define XFG_SEG_BITS 0
+#endif
+#ifndef XFG_SEG_LONG
+#define XFG_SEG_LONG 208
+#endif
+#ifndef XFG_SEG_MID
+#define XFG_SEG_MID 160
+#endif
+#ifndef XFG_SEG_SHORT
+#define XFG_SEG_SHORT 128
 #endif
 #ifndef XFG_OUT_LDS
 #define XFG_OUT_LDS 2304
 #endif
 #ifndef XFG_TOK_MAX
-#define XFG_TOK_MAX 240
+#define XFG_TOK_MAX 240               // match tokens per round at the middle segment size; the list takes what the window leaves
 #endif
 #ifndef XFG_SPEC_BACK
 #define XFG_SPEC_BACK 0               // run-in of the speculative walk, bits before its segment, dynamic blocks
@@ -96,32 +110,39 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_ACCEPT_FD
 #define XFG_ACCEPT_FD 56              // settle for a verified prefix of this many lanes (64 = insist on all)
 #endif
-constexpr int SEG_BITS = XFG_SEG_BITS;  // bits of compressed stream per lane and batch
-constexpr int BATCH_BYTES = 64 * SEG_BITS / 8;
+constexpr int SEG_MAX = XFG_SEG_BITS ? XFG_SEG_BITS : XFG_SEG_LONG;   // the longest segment: sizes the LDS windows
+constexpr int SEG_MIN = XFG_SEG_BITS ? XFG_SEG_BITS : XFG_SEG_SHORT;
+constexpr int BATCH_BYTES = 64 * SEG_MAX / 8;
 constexpr int BWIN_BYTES = (BATCH_BYTES + 64) > 1024 ? (BATCH_BYTES + 64) : 1024;   // batch window: 16-byte alignment slack + over-read; >= the header ring
 constexpr int NPF = (BWIN_BYTES + 1023) / 1024;     // 16-byte units per lane that cover the batch window
 constexpr int OUT_LDS = XFG_OUT_LDS;    // bytes of batch output staged in LDS
 constexpr int OUT_CAP = OUT_LDS - 258;  // a lane stops at the token that takes it to OUT_CAP: one lane always fits
-constexpr int TOK_MAX = XFG_TOK_MAX;    // match tokens per batch
+// The compressed window and the match-token list share one LDS region: the window of a batch of
+// seg_bits-bit segments is 8 * seg_bits + 64 bytes, the list (6 bytes per token) takes the rest.
+constexpr int WT_BYTES = (8 * (XFG_SEG_BITS ? XFG_SEG_BITS : XFG_SEG_MID) + 64 + 6 * XFG_TOK_MAX + 7) / 8 * 8;
+constexpr int TOK_MIN = (WT_BYTES - BWIN_BYTES) / 6;            // tokens per round at the longest segment size
 constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix (careful path)
 #ifndef XFG_MAX_FIX
 #define XFG_MAX_FIX 5
+#endif
+#ifndef XFG_MAX_FIX_FIXED
+#define XFG_MAX_FIX_FIXED 12          // fixed blocks: every walk adds about two lanes to the chain, and costs less than a new batch
 #endif
 #ifndef XFG_LONG_MATCH
 #define XFG_LONG_MATCH 64
 #endif
 constexpr int LONG_MATCH = XFG_LONG_MATCH;   // matches this long are copied by the whole wave, one at a time
 constexpr int SERIAL_ENTER = 6;         // a parallel batch that keeps this few lanes switches the block to serial batches
-constexpr int SERIAL_BITS = (2 * TOK_MAX < 64 * SEG_BITS) ? 2 * TOK_MAX : 64 * SEG_BITS;   // a match token is >= 2 bits: the list cannot overflow
 #ifndef XFG_ACCEPT_PASS
 #define XFG_ACCEPT_PASS 2
 #endif
 constexpr int ACCEPT_PASS = XFG_ACCEPT_PASS;   // after this many walks from corrected starts, a chain of XFG_ACCEPT_FD lanes is good enough
 constexpr int MAX_FIX = XFG_MAX_FIX;    // re-synchronisation walks per batch before settling for the stable prefix
-constexpr int MASK_WORDS = (SEG_BITS + 48 + 31) / 32;   // a path ends less than 48 bits after its segment
+constexpr int MASK_WORDS = (SEG_MAX + 48 + 31) / 32;    // a path ends less than 48 bits after its segment
 static_assert(MASK_WORDS * 64 * 4 <= OUT_LDS, "the token-start masks share the output window's LDS");
 static_assert(OUT_CAP >= 1024, "output window too small");
-static_assert(TOK_MAX >= SEG_BITS / 2, "one lane's tokens (>= 2 bits each) must fit the token list");
+static_assert(WT_BYTES > BWIN_BYTES && TOK_MIN >= SEG_MAX / 2, "one lane's tokens (>= 2 bits each) must fit the token list");
+static_assert(SEG_MIN >= 64 && SEG_MIN <= XFG_SEG_MID && XFG_SEG_MID <= SEG_MAX, "segment sizes");
 static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
 
 // Table entry (u32): what one decode step does with the bits at the head of the buffer.
@@ -192,7 +213,8 @@ struct HeaderScratch {
 };
 struct alignas(16) WaveLds {
     u32 tab[LIT_TAB + DIST_TAB];    // literal/length table at 0, distance table at LIT_TAB
-    u64 win[BWIN_BYTES / 8];        // batch window; its first WIN_BYTES double as the header reader's ring
+    u64 win[WT_BYTES / 8];          // batch window, then the batch's match tokens (token_list()); the first WIN_BYTES
+                                    // double as the header reader's ring
     union {
         u64 out[OUT_LDS / 8 + 10];  // output of the current batch at [woff, woff + n), woff = its HBM address mod 16, so that
                                     // the flush is 16-byte aligned on both sides (+ 64 bytes that nobody reads)
@@ -200,13 +222,26 @@ struct alignas(16) WaveLds {
         u32 mask[MASK_WORDS * 64];  // synchronisation passes only (before anything is emitted): token-start bits of
                                     // every lane's speculative path, word w of lane l at [w * 64 + l]
     };
-    u32 tok[TOK_MAX];               // match tokens of the batch, stream order: (len-3) | (dist-1) << 8
-    u16 tdst[TOK_MAX];              // their destinations in the output window
 #ifdef XFG_PROFILE
     unsigned long long prof[PF_COUNTERS];
 #endif
 };
 static_assert(sizeof(HeaderScratch) <= OUT_LDS, "header scratch must fit the output window");
+
+// The match tokens of one round, behind the compressed window of a batch of seg_bits-bit segments.
+struct TokList {
+    u32 *tok;           // stream order: (len-3) | (dist-1) << 8
+    u16 *tdst;          // their destinations in the output window
+    u32 max;            // tokens per round
+};
+__device__ __forceinline__ TokList token_list(WaveLds &L, u32 seg_bits) {
+    const u32 bwin = 8 * seg_bits + 64;
+    TokList t;
+    t.max = ((u32)WT_BYTES - bwin) / 6;
+    t.tok = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(L.win) + bwin);
+    t.tdst = reinterpret_cast<u16 *>(t.tok + t.max);
+    return t;
+}
 
 #ifdef XFG_PROFILE
 // Accumulated per wave in LDS (WaveLds::prof) and added to the global array once per chunk,
@@ -783,7 +818,7 @@ __device__ __forceinline__ void store_batch_window(WaveLds &L, u32 lane, const u
 //   TAIL = true: the batch may run past the end of the stream; every read of the reference
 //   that can fail with io.ErrUnexpectedEOF is checked at the same point.
 template <bool EMIT>
-__device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
+__device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, const TokList tl, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
                                                    bool dist_empty, u32 orel, u32 obase, u32 moff, u32 &err_out)
 {
     const u32 *win = reinterpret_cast<const u32 *>(L.win);
@@ -830,8 +865,8 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, i32 wb0, u32 star
                 const u32 dst = obase + nout;
                 const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;      // dictDecoder.HistSize
                 if (value > hist) { pos += take; flag = F_DIST; err_out = nout; break; }   // flate/reader.go:223-225
-                L.tok[moff + nm] = (len - 3) | ((value - 1) << 8);
-                L.tdst[moff + nm] = (u16)(orel + nout);
+                tl.tok[moff + nm] = (len - 3) | ((value - 1) << 8);
+                tl.tdst[moff + nm] = (u16)(orel + nout);
             }
         }
         tbase = is_sub ? val - tab_lds : (is_len ? 4u * LIT_TAB : 0u);
@@ -860,7 +895,7 @@ struct __attribute__((packed)) PackedU64 { u64 v; };             // 8 bytes at a
 typedef const __attribute__((address_space(3))) PackedU64 *lds_cpu64p;
 
 template <bool EMIT>
-__device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 start, u32 seg_end,
+__device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl, i32 wb0, u32 start, u32 seg_end,
                                                    u32 orel, u32 obase, u32 moff, u32 lane, u32 &err_out)
 {
     // LDS byte addresses: the lookup state is the address of the table the next step indexes
@@ -903,8 +938,8 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, i32 wb0, u32 star
                     const u32 dst = obase + nout;
                     const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;  // dictDecoder.HistSize
                     bad = value > hist ? 0x80000000u : 0u;                       // flate/reader.go:223-225
-                    L.tok[moff + nm] = (len - 3) | ((value - 1) << 8);
-                    L.tdst[moff + nm] = (u16)(orel + nout);
+                    tl.tok[moff + nm] = (len - 3) | ((value - 1) << 8);
+                    tl.tdst[moff + nm] = (u16)(orel + nout);
                 }
             }
             tb = SEL(m_sub, val, SEL(m_len, tab1, tab0));
@@ -938,7 +973,7 @@ out:
 //                  that path's end is its end (returns merged = true), or until its own end.
 // Returns the bit position after the last token; e_out = the entry that ended the walk.
 template <bool CHECK, bool RUNIN>
-__device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 seg_start, u32 lane,
+__device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 seg_start, u32 seg_bits, u32 lane,
                                             u32 &e_out, bool &merged)
 {
     const u32 tab0 = (u32)(uintptr_t)(lds_cu32p)L.tab;
@@ -992,7 +1027,7 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
                 }
             }
             tokprev = m_tok;
-            const u32 over = (u32)(SEG_BITS - 1) - rel;         // negative = at or past the segment end
+            const u32 over = seg_bits - 1 - rel;                // negative = at or past the segment end
             if ((i32)((over & m_tok) | e) < 0) goto out;
         }
     }
@@ -1168,13 +1203,13 @@ struct PreLoad {
     u32 n_sh;       // bytes fetched (0 = nothing to do) | sh << 8
     u32 g;          // bytes of the match that come from before the window (all of them, not just the first 16)
 };
-__device__ __forceinline__ PreLoad pre_load(const u8 *raw, const u8 *gwin, u32 woff, const WaveLds &L, u32 m, u32 M) {
+__device__ __forceinline__ PreLoad pre_load(const u8 *raw, const u8 *gwin, u32 woff, const TokList tl, u32 m, u32 M) {
     PreLoad p;
     p.tok = 0; p.dpos = 0; p.n_sh = 0; p.g = 0;
     const u8 *pa = raw, *pb = raw;                              // a lane without work reads the chunk's first bytes
     if (m < M) {
-        const u32 t = L.tok[m];
-        const u32 d = L.tdst[m];
+        const u32 t = tl.tok[m];
+        const u32 d = tl.tdst[m];
         p.tok = t; p.dpos = d;
         const u32 len = (t & 255) + 3, dist = (t >> 8) + 1;
         const i32 s = (i32)d - (i32)dist;
@@ -1228,14 +1263,14 @@ __device__ __forceinline__ void pre_store(u8 *outw, const u8 *gwin, const PreLoa
 }
 // After its bytes from before the window are in place: does the token still need bytes from inside the
 // window (or is it a long one, which the wave copies whole)?  Those move up to the front of the list.
-__device__ __forceinline__ u32 pre_compact(WaveLds &L, const PreLoad &p, bool have, u32 K, u32 lane) {
+__device__ __forceinline__ u32 pre_compact(const TokList tl, const PreLoad &p, bool have, u32 K, u32 lane) {
     const u32 len = (p.tok & 255) + 3;
     const bool need = have && (len >= (u32)LONG_MATCH || p.g < len);
     const u64 nm = __ballot(need);
     if (need) {
         const u32 k = K + (u32)__popcll(nm & ((1ull << lane) - 1));
-        L.tok[k] = p.tok;
-        L.tdst[k] = (u16)p.dpos;
+        tl.tok[k] = p.tok;
+        tl.tdst[k] = (u16)p.dpos;
     }
     return K + (u32)__popcll(nm);
 }
@@ -1253,7 +1288,7 @@ __device__ __forceinline__ u32 pre_compact(WaveLds &L, const PreLoad &p, bool ha
 // beyond its foreign source bytes it has written itself.  Matches of LONG_MATCH bytes and more
 // are not copied by their lane: when such a token is the first unresolved one, the whole wave
 // copies it (copy_long_match).
-__device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveLds &L, u32 M, u32 lane) {
+__device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveLds &L, const TokList tl, u32 M, u32 lane) {
     u8 *outw = reinterpret_cast<u8 *>(L.out);
     const u8 *gwin = raw + base - woff;                         // HBM address of window position 0
     u32 rounds = 0;
@@ -1262,19 +1297,19 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
     if (swept) {
         u32 K = 0;
         for (u32 r0 = 0; r0 < M; r0 += 256) {
-            const PreLoad p0 = pre_load(raw, gwin, woff, L, r0 + lane, M);
-            const PreLoad p1 = pre_load(raw, gwin, woff, L, r0 + 64 + lane, M);
-            const PreLoad p2 = pre_load(raw, gwin, woff, L, r0 + 128 + lane, M);
-            const PreLoad p3 = pre_load(raw, gwin, woff, L, r0 + 192 + lane, M);
+            const PreLoad p0 = pre_load(raw, gwin, woff, tl, r0 + lane, M);
+            const PreLoad p1 = pre_load(raw, gwin, woff, tl, r0 + 64 + lane, M);
+            const PreLoad p2 = pre_load(raw, gwin, woff, tl, r0 + 128 + lane, M);
+            const PreLoad p3 = pre_load(raw, gwin, woff, tl, r0 + 192 + lane, M);
             wave_sync();                                        // all four rounds' tokens are read before the list is compacted
             pre_store(outw, gwin, p0);
-            K = pre_compact(L, p0, r0 + lane < M, K, lane);
+            K = pre_compact(tl, p0, r0 + lane < M, K, lane);
             pre_store(outw, gwin, p1);
-            K = pre_compact(L, p1, r0 + 64 + lane < M, K, lane);
+            K = pre_compact(tl, p1, r0 + 64 + lane < M, K, lane);
             pre_store(outw, gwin, p2);
-            K = pre_compact(L, p2, r0 + 128 + lane < M, K, lane);
+            K = pre_compact(tl, p2, r0 + 128 + lane < M, K, lane);
             pre_store(outw, gwin, p3);
-            K = pre_compact(L, p3, r0 + 192 + lane < M, K, lane);
+            K = pre_compact(tl, p3, r0 + 192 + lane < M, K, lane);
         }
         wave_sync();
         M = K;
@@ -1285,8 +1320,8 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
         const bool have = m < M;
         u32 d = 0, len = 0, dist = 1;
         if (have) {
-            const u32 t = L.tok[m];
-            d = L.tdst[m];
+            const u32 t = tl.tok[m];
+            d = tl.tdst[m];
             len = (t & 255) + 3;
             dist = (t >> 8) + 1;
         }
@@ -1371,8 +1406,20 @@ struct BlockEnd {
 };
 
 // Decode one Huffman block that starts at bit position p0.  Output goes to o.raw at o.pos.
+// Segment size for the next batch from the last one's expansion (output bytes per compressed byte).
+__device__ __forceinline__ u32 seg_bits_for(u32 out_bytes, u32 in_bits) {
+#if XFG_SEG_BITS
+    return XFG_SEG_BITS;
+#else
+    const u32 out_bits = out_bytes * 8;                         // (a batch's output is far below 2^29 bytes)
+    if (2 * out_bits < 3 * in_bits) return XFG_SEG_LONG;        // below 1.5: literals dominate
+    if (out_bits < 4 * in_bits) return XFG_SEG_MID;
+    return XFG_SEG_SHORT;                                       // 4 and more: matches dominate
+#endif
+}
+
 __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u32 lane, u32 p0,
-                                         int lit_state, int dist_state, u32 spec_back)
+                                         int lit_state, int dist_state, u32 spec_back, u32 max_fix, u32 &seg_bits)
 {
     BlockEnd be;
     if (lit_state == 1) { be.status = XFG_ST_CORRUPTED; be.bitpos = p0; return be; }   // empty literal tree
@@ -1406,9 +1453,11 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         const u32 woff = (u32)((uintptr_t)(o.raw + o.pos) & 15);  // window position of the batch's first byte
         u32 err_out = 0;
         bool emitted = false;
-        u32 start = p0 + lane * SEG_BITS;
+        u32 start = p0 + lane * seg_bits;
         const u32 seg_start = start;
-        u32 seg_end = p0 + (lane + 1) * SEG_BITS;
+        u32 seg_end = p0 + (lane + 1) * seg_bits;
+        const u32 pos0 = o.pos;
+        const TokList tl = token_list(L, seg_bits);
         bool dirty = true, dead = false;
         Seg sg;
         sg.end = start; sg.nout = 0; sg.nmatch = 0; sg.flag = F_NONE;
@@ -1417,11 +1466,11 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         if (!tail && serial) {
             // ---- a few tokens fill the whole output window (long matches): speculation would be thrown
             // away, so lane 0 walks the batch's bits alone until the window is full
-            seg_end = p0 + (u32)SERIAL_BITS;
+            seg_end = p0 + 2 * tl.max;                          // a match token is >= 2 bits: the list cannot overflow
             dead = lane != 0;
             start = p0;
             // (alone, its offsets are known: this walk is the emit pass already)
-            if (!dead) sg = decode_segment_fast<true>(L, wb0, start, seg_end, woff, o.pos, 0, lane, err_out);
+            if (!dead) sg = decode_segment_fast<true>(L, tl, wb0, start, seg_end, woff, o.pos, 0, lane, err_out);
             emitted = true;
             wave_sync();
             PROF_CNT(PF_N_PASS, 1, lane);
@@ -1444,9 +1493,9 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                     // the walk starts before its segment: by the segment's first bit it has usually met the true
                     // path.  The run-in never reaches back beyond p0, a true start.
                     start = seg_start - p0 > spec_back ? seg_start - spec_back : p0;
-                    endA = sync_segment<false, true>(L, wb0, start, seg_start, lane, eA, mg);
+                    endA = sync_segment<false, true>(L, wb0, start, seg_start, seg_bits, lane, eA, mg);
                 } else {
-                    endA = sync_segment<false, false>(L, wb0, start, seg_start, lane, eA, mg);
+                    endA = sync_segment<false, false>(L, wb0, start, seg_start, seg_bits, lane, eA, mg);
                 }
                 PROF_ADD(PF_P_SPEC, lane);
             }
@@ -1465,11 +1514,11 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 const u64 dm = __ballot(dirty);
                 if (dm == 0) { verified = 64; break; }
                 const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
-                if (pass > MAX_FIX || fd >= want || (pass > ACCEPT_PASS && fd >= (u32)XFG_ACCEPT_FD)) { verified = fd; break; }
+                if ((u32)pass > max_fix || fd >= want || (pass > ACCEPT_PASS && fd >= (u32)XFG_ACCEPT_FD)) { verified = fd; break; }
                 {
                     PROF_T0();
                     if (dirty && !dead) {
-                        const u32 en = sync_segment<true, false>(L, wb0, start, seg_start, lane, e1, mg);
+                        const u32 en = sync_segment<true, false>(L, wb0, start, seg_start, seg_bits, lane, e1, mg);
                         end = mg ? endA : en;
                         stop = mg ? stopA : (e1 & E_STOP);
                     }
@@ -1480,7 +1529,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             }
             wave_sync();                                        // the masks share LDS with the output window
             // ---- stage 1a': count bytes and matches along the true path
-            { PROF_T0(); if (!dead && lane < verified) sg = decode_segment_fast<false>(L, wb0, start, seg_end, 0, 0, 0, lane, dummy); PROF_ADD(PF_P_COUNT, lane); }
+            { PROF_T0(); if (!dead && lane < verified) sg = decode_segment_fast<false>(L, tl, wb0, start, seg_end, 0, 0, 0, lane, dummy); PROF_ADD(PF_P_COUNT, lane); }
             PROF_CNT(PF_N_PASS, 1, lane);
             // Whatever the walks above concluded, only a chain that closes is kept: every lane must start
             // where its predecessor's counted path ended (a lane that stopped at the output cap ends early).
@@ -1495,7 +1544,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             // ---- stage 1a (careful): speculative passes until the chain of segment starts is stable
             for (int pass = 1;; pass++) {
                 if (dirty && !dead)
-                    sg = decode_segment_tail<false>(L, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
+                    sg = decode_segment_tail<false>(L, tl, wb0, start, seg_end, total_bits, dist_empty, 0, 0, 0, dummy);
                 PROF_CNT(PF_N_PASS, 1, lane);
                 const u32 pe = lane_prev(sg.end);
                 const u32 pfl = lane_prev(sg.flag);
@@ -1525,7 +1574,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         u32 lflag = F_NONE, lend = p0;
         for (u32 b0 = 0;;) {
             const u32 rel = rel0 - lane_get(rel0, b0), moff = moff0 - lane_get(moff0, b0);   // (wraps below b0: those lanes are not kept)
-            const bool keep = live && lane >= b0 && rel + sg.nout <= (u32)OUT_LDS && moff + sg.nmatch <= (u32)TOK_MAX;
+            const bool keep = live && lane >= b0 && rel + sg.nout <= (u32)OUT_LDS && moff + sg.nmatch <= tl.max;
             u32 nkeep = (u32)__popcll(__ballot(keep));          // >= 1: one lane always fits
 #if !XFG_SUBBATCH
             const bool final = true;
@@ -1565,8 +1614,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             {
                 PROF_T0();
                 if (keep && !emitted) {
-                    if (tail) fin = decode_segment_tail<true>(L, wb0, start, seg_end, total_bits, dist_empty, wo + rel, o.pos + rel, moff, err_out);
-                    else      fin = decode_segment_fast<true>(L, wb0, start, seg_end, wo + rel, o.pos + rel, moff, lane, err_out);
+                    if (tail) fin = decode_segment_tail<true>(L, tl, wb0, start, seg_end, total_bits, dist_empty, wo + rel, o.pos + rel, moff, err_out);
+                    else      fin = decode_segment_fast<true>(L, tl, wb0, start, seg_end, wo + rel, o.pos + rel, moff, lane, err_out);
                 }
                 wave_sync();
                 PROF_ADD(PF_EMIT, lane);
@@ -1586,7 +1635,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 PROF_T0();
                 mem_sync();                                     // earlier rounds' flushed bytes are read back here
                 PROF_ADD(PF_R_SYNC, lane);
-                resolve_tokens(o.raw, o.cap, o.pos, wo, L, M, lane);
+                resolve_tokens(o.raw, o.cap, o.pos, wo, L, tl, M, lane);
                 PROF_ADD(PF_RESOLVE, lane);
             }
             // ---- flush to HBM (never beyond the chunk's capacity)
@@ -1621,6 +1670,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         if (lflag == F_CORRUPT) { be.status = XFG_ST_CORRUPTED; be.bitpos = lend; return be; }
         if (lflag == F_EOF) { be.status = XFG_ST_UNEXPECTED_EOF; be.bitpos = lend; return be; }
         if (lflag != F_NONE || lend <= p0) { be.status = XFG_ST_INTERNAL; be.bitpos = lend; return be; }
+        if (!tail && !serial) seg_bits = seg_bits_for(o.pos - pos0, lend - p0);
         p0 = lend;                                                 // next batch
     }
 }
@@ -1655,6 +1705,8 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
     o.pos = 0;
 
     const bool rfc_rep16 = (flags & XFG_CHUNK_RFC_REP16) != 0;
+    // the first batch's segment size from the chunk's own sizes, where the index vouches for them
+    u32 seg_bits = (flags & XFG_CHUNK_VERIFY) ? seg_bits_for(o.cap, r.csize * 8u) : (u32)XFG_SEG_MID;
     int status;
     int tables = 0;                                             // 0 none, 1 fixed, 2 dynamic
 
@@ -1711,7 +1763,8 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
             }
             PROF_CNT(PF_N_BLOCKS, 1, lane);
             const BlockEnd be = decode_huffman_block(r, o, L, lane, reader_bitpos(r), lit_state, dist_state,
-                                                     btype == 1 ? (u32)XFG_SPEC_BACK_FIXED : (u32)XFG_SPEC_BACK);
+                                                     btype == 1 ? (u32)XFG_SPEC_BACK_FIXED : (u32)XFG_SPEC_BACK,
+                                                     btype == 1 ? (u32)XFG_MAX_FIX_FIXED : (u32)MAX_FIX, seg_bits);
             wave_sync();
             reader_seek(r, be.bitpos);                          // the window was reused by the block decoder
             status = be.status;
