@@ -51,6 +51,7 @@ WORKLOADS = {
     "huffman": (16384, 65536, ("huffman",), 6, 256),
     "repeats": (16384, 65536, ("repeats",), 6, 256),
     "digits": (16384, 65536, ("digits",), 6, 256),
+    "text": (16384, 65536, ("text",), 6, 64),           # English text (twain.txt), dynamic blocks
     "zeros": (16384, 65536, ("zeros",), 6, 4),
     "random": (16384, 65536, ("random",), 6, 256),
     # C4: match-copy-bound, 1 MiB chunks written token by token (258-byte matches at 1-32 KiB distances; dist-1 runs)

@@ -92,6 +92,12 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_SEG_SHORT
 #define XFG_SEG_SHORT 128
 #endif
+#ifndef XFG_EXP_LONG_X4
+#define XFG_EXP_LONG_X4 6             // expansion (x4) below which a batch is followed by long segments
+#endif
+#ifndef XFG_EXP_SHORT_X4
+#define XFG_EXP_SHORT_X4 16           // expansion (x4) from which on it is followed by short ones
+#endif
 #ifndef XFG_OUT_LDS
 #define XFG_OUT_LDS 2304
 #endif
@@ -142,7 +148,7 @@ constexpr int MASK_WORDS = (SEG_MAX + 48 + 31) / 32;    // a path ends less than
 static_assert(MASK_WORDS * 64 * 4 <= OUT_LDS, "the token-start masks share the output window's LDS");
 static_assert(OUT_CAP >= 1024, "output window too small");
 static_assert(WT_BYTES > BWIN_BYTES && TOK_MIN >= SEG_MAX / 2, "one lane's tokens (>= 2 bits each) must fit the token list");
-static_assert(SEG_MIN >= 64 && SEG_MIN <= XFG_SEG_MID && XFG_SEG_MID <= SEG_MAX, "segment sizes");
+static_assert(SEG_MIN >= 64 && (XFG_SEG_BITS || (SEG_MIN <= XFG_SEG_MID && XFG_SEG_MID <= SEG_MAX)), "segment sizes");
 static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
 
 // Table entry (u32): what one decode step does with the bits at the head of the buffer.
@@ -1412,8 +1418,8 @@ __device__ __forceinline__ u32 seg_bits_for(u32 out_bytes, u32 in_bits) {
     return XFG_SEG_BITS;
 #else
     const u32 out_bits = out_bytes * 8;                         // (a batch's output is far below 2^29 bytes)
-    if (2 * out_bits < 3 * in_bits) return XFG_SEG_LONG;        // below 1.5: literals dominate
-    if (out_bits < 4 * in_bits) return XFG_SEG_MID;
+    if (4 * out_bits < (u32)XFG_EXP_LONG_X4 * in_bits) return XFG_SEG_LONG;    // below 1.5: literals dominate
+    if (4 * out_bits < (u32)XFG_EXP_SHORT_X4 * in_bits) return XFG_SEG_MID;
     return XFG_SEG_SHORT;                                       // 4 and more: matches dominate
 #endif
 }
