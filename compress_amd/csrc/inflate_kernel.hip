@@ -1417,9 +1417,9 @@ __device__ __forceinline__ u32 seg_bits_for(u32 out_bytes, u32 in_bits) {
 #if XFG_SEG_BITS
     return XFG_SEG_BITS;
 #else
-    const u32 out_bits = out_bytes * 8;                         // (a batch's output is far below 2^29 bytes)
-    if (4 * out_bits < (u32)XFG_EXP_LONG_X4 * in_bits) return XFG_SEG_LONG;    // below 1.5: literals dominate
-    if (4 * out_bits < (u32)XFG_EXP_SHORT_X4 * in_bits) return XFG_SEG_MID;
+    const u64 out_x4 = (u64)out_bytes * 32;                     // output bits times four (a whole chunk's sizes come through here too)
+    if (out_x4 < (u64)XFG_EXP_LONG_X4 * in_bits) return XFG_SEG_LONG;          // below 1.5: literals dominate
+    if (out_x4 < (u64)XFG_EXP_SHORT_X4 * in_bits) return XFG_SEG_MID;
     return XFG_SEG_SHORT;                                       // 4 and more: matches dominate
 #endif
 }
