@@ -125,6 +125,29 @@ def cpu_baseline(shard, threads):
     return dt, bad, raw
 
 
+def zlib_baseline(shard, threads):
+    """System C zlib (raw inflate) over the same chunks on host threads: the second CPU figure SURVEY 8(d) asks for."""
+    import zlib
+    n = shard["n"]
+    comp = memoryview(shard["comp"])
+    descs = shard["descs"]
+    per = (n + threads - 1) // threads
+    end_block = b"\x01\x00\x00\xff\xff"
+
+    def work(t):
+        bad = 0
+        for i in range(t * per, min(n, (t + 1) * per)):
+            d = descs[i]
+            out = zlib.decompressobj(-15).decompress(bytes(comp[d.comp_off:d.comp_off + d.comp_size]) + end_block)
+            bad += len(out) != d.raw_size
+        return bad
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        bad = sum(ex.map(work, range(threads)))
+    return time.perf_counter() - t0, bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +292,11 @@ def main():
                                    "sample": "this rank's whole shard %d times (%d chunks, %.2f GiB raw each), "
                                              "oracle/inflate_oracle.c over %d host threads, %.1f s wall; %d bad chunks"
                                              % (reps, n, raw_len / 2**30, threads, total_dt, bad)}
+            zdt, zbad = zlib_baseline(shard, threads)
+            out["cpu_baseline"]["zlib"] = {"value": round(raw_len / zdt / 1e9, 3), "unit": "GB/s", "cores": threads,
+                                           "sample": "the same shard once, system zlib %s raw inflate through Python's zlib module "
+                                                     "over %d host threads, %.1f s wall; %d bad chunks"
+                                                     % (__import__("zlib").ZLIB_RUNTIME_VERSION, threads, zdt, zbad)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
