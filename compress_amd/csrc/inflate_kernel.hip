@@ -4,8 +4,9 @@
 // workgroup is one wave.  The grid is persistent (as many workgroups as fit the
 // CUs' LDS); every wave draws its next chunk from a counter, expensive chunks first.
 //
-// Inside a Huffman block the 64 lanes work on 64 consecutive SEG_BITS-bit segments
-// of the bit stream at once (decode_huffman_block), one "batch" per iteration:
+// Inside a Huffman block the 64 lanes work on 64 consecutive segments of the bit stream
+// at once (decode_huffman_block), one "batch" per iteration; the segment size (128, 160 or
+// 208 bits) is chosen per batch from the expansion of the batch before it (seg_bits_for):
 //   stage 1  a. speculative walk: lane i starts at segment boundary i, which is almost
 //               never a code-word boundary, and marks every bit position where one of
 //               its tokens starts (sync_segment<false>).  Prefix codes self-synchronise,

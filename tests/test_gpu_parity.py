@@ -278,6 +278,25 @@ def test_generated_streams_match_oracle(ctx, orc, kind, level, strategy):
     _roundtrip(ctx, orc, stream, b"".join(raws))
 
 
+@pytest.mark.parametrize("level,strategy", [(6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED)])
+def test_chunks_that_change_character(ctx, orc, level, strategy):
+    """The kernel picks its segment size (208 / 160 / 128 bits) per batch from the expansion of the batch
+    before it.  These chunks switch between literal-heavy, mixed and match-heavy data every few KB, also
+    inside one DEFLATE block, so that every transition between sizes is taken; results must not depend on it."""
+    from compress_amd import synth
+    rng = random.Random(level * 31 + strategy)
+    raws = []
+    for i in range(24):
+        parts = []
+        while sum(map(len, parts)) < 40000 + 9000 * (i % 5):
+            kind = rng.choice(["huffman", "repeats", "digits", "zeros", "random", "huffman", "digits"])
+            parts.append(synth.GENERATORS[kind](rng.choice([700, 2000, 5000, 12000, 30000]), 1000 * i + len(parts)))
+        raws.append(b"".join(parts))
+    comps = [synth.deflate_chunk(r, level, strategy) for r in raws]
+    stream = synth.assemble_stream(comps, [len(r) for r in raws], index_size=7)
+    _roundtrip(ctx, orc, stream, b"".join(raws))
+
+
 def test_twain_default_chunks(ctx, orc):
     """BASELINE config C1: twain.txt, default 256 KiB chunk size (chunks of 262144 + 125825 bytes)."""
     from compress_amd import xflate, capi
