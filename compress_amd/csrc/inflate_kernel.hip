@@ -132,6 +132,12 @@ constexpr int MAX_PASSES = 6;           // speculative passes before settling fo
 #ifndef XFG_MAX_FIX
 #define XFG_MAX_FIX 5
 #endif
+#ifndef XFG_STORED_DEEP
+#define XFG_STORED_DEEP 1
+#endif
+#ifndef XFG_STORED_SYNC
+#define XFG_STORED_SYNC 0
+#endif
 #ifndef XFG_MAX_FIX_FIXED
 #define XFG_MAX_FIX_FIXED 12          // fixed blocks: every walk adds about two lanes to the chain, and costs less than a new batch
 #endif
@@ -294,6 +300,23 @@ struct Reader {
     u32 lane;
 };
 
+// Eight bytes of the virtual stream  chunk || 01 00 00 ff ff (xflate/common.go:57) || zeros  at stream
+// index ci, where p, the address that index has, is 8-byte aligned.  An aligned word lies in one page:
+// loading a word that holds at least one byte of the chunk cannot fault, whatever follows the chunk in
+// memory, and what is not the chunk's is masked out.  Bytes before the chunk's start (ci < 0) come out as
+// whatever memory holds (the previous chunk); nobody consumes them.
+__device__ __forceinline__ u64 stream_word(const Reader &r, const u8 *p, i64 ci) {
+    const i64 k = (i64)r.csize - ci;                            // bytes of the chunk from ci on: >= 8 all of the word, <= 0 none
+    u64 w = 0;
+    if (k > 0 && ci + 8 > 0) w = *reinterpret_cast<const u64 *>(p);
+    if (k < 8) {
+        const u64 eb = r.total > r.csize ? 0xffff000001ull : 0ull;
+        if (k > 0) w = (w & ((1ull << (8 * k)) - 1)) | (eb << (8 * k));
+        else w = k > -5 ? eb >> (8 * (-k)) : 0ull;
+    }
+    return w;
+}
+
 __device__ __forceinline__ void win_load(Reader &r, i32 k) {
     // Block k covers window positions [512k, 512k+512); window position q = lead + stream byte index.
     const u32 q0 = (u32)k * 512u + r.lane * 8u;
@@ -304,20 +327,7 @@ __device__ __forceinline__ void win_load(Reader &r, i32 k) {
         // before the chunk start (ci < 0) belong to the previous chunk and are never consumed.
         w = *reinterpret_cast<const u64 *>(r.comp + r.base_al + q0);
     } else {
-        // Tail: chunk bytes, then 01 00 00 ff ff (xflate/common.go:57), then zeros.
-        w = 0;
-        for (int j = 0; j < 8; j++) {
-            const i64 idx = ci + j;
-            u32 b = 0;
-            if (idx >= 0) {
-                if (idx < (i64)r.csize) b = r.comp[r.base_al + q0 + j];
-                else if (idx < (i64)r.total) {
-                    const u32 t = (u32)(idx - r.csize);       // 0..4
-                    b = (t == 0) ? 0x01u : (t >= 3 ? 0xffu : 0x00u);
-                }
-            }
-            w |= (u64)b << (8 * j);
-        }
+        w = stream_word(r, r.comp + r.base_al + q0, ci);
     }
     r.win[(k & 1) * 64 + r.lane] = w;
 }
@@ -548,13 +558,36 @@ __device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32
     if (lane < head) dst[lane] = src[lane];
     const u32 body = (fast - head) >> 4;
     u32 i = lane;
-    for (; i + 192 < body; i += 256) {                          // four loads in flight per lane
-        uint4 v0, v1, v2, v3;
-        __builtin_memcpy(&v0, src + head + (size_t)i * 16, 16);
+#if XFG_STORED_DEEP
+    for (; i + 448 < body; i += 512) {                          // eight loads in flight per lane
+        uint4 v0, v1, v2, v3, v4, v5, v6, v7;
+        __builtin_memcpy(&v0, src + head + (size_t)(i + 0) * 16, 16);
         __builtin_memcpy(&v1, src + head + (size_t)(i + 64) * 16, 16);
         __builtin_memcpy(&v2, src + head + (size_t)(i + 128) * 16, 16);
         __builtin_memcpy(&v3, src + head + (size_t)(i + 192) * 16, 16);
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)i * 16) = v0;
+        __builtin_memcpy(&v4, src + head + (size_t)(i + 256) * 16, 16);
+        __builtin_memcpy(&v5, src + head + (size_t)(i + 320) * 16, 16);
+        __builtin_memcpy(&v6, src + head + (size_t)(i + 384) * 16, 16);
+        __builtin_memcpy(&v7, src + head + (size_t)(i + 448) * 16, 16);
+        asm volatile("" ::: "memory");                          // all loads are issued before the first store
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 0) * 16) = v0;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 64) * 16) = v1;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 128) * 16) = v2;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 192) * 16) = v3;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 256) * 16) = v4;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 320) * 16) = v5;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 384) * 16) = v6;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 448) * 16) = v7;
+    }
+#endif
+    for (; i + 192 < body; i += 256) {                          // four
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, src + head + (size_t)(i + 0) * 16, 16);
+        __builtin_memcpy(&v1, src + head + (size_t)(i + 64) * 16, 16);
+        __builtin_memcpy(&v2, src + head + (size_t)(i + 128) * 16, 16);
+        __builtin_memcpy(&v3, src + head + (size_t)(i + 192) * 16, 16);
+        asm volatile("" ::: "memory");                          // all loads are issued before the first store
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 0) * 16) = v0;
         *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 64) * 16) = v1;
         *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 128) * 16) = v2;
         *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 192) * 16) = v3;
@@ -785,20 +818,8 @@ __device__ __forceinline__ void fetch_batch_window(const Reader &r, i32 wb0, u32
             if (ci >= 0 && ci + 16 <= (i32)r.csize) {
                 v = *reinterpret_cast<const uint4 *>(src + ci);
             } else if (ci + 16 > 0 && ci < (i32)r.total) {
-                u32 w[4] = {0, 0, 0, 0};
-                for (int j = 0; j < 16; j++) {
-                    const i32 idx = ci + j;
-                    u32 bb = 0;
-                    if (idx >= 0) {
-                        if (idx < (i32)r.csize) bb = src[idx];
-                        else if (idx < (i32)r.total) {
-                            const u32 t = (u32)idx - r.csize;   // 01 00 00 ff ff (xflate/common.go:57)
-                            bb = (t == 0) ? 0x01u : (t >= 3 ? 0xffu : 0x00u);
-                        }
-                    }
-                    w[j >> 2] |= bb << (8 * (j & 3));
-                }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+                const u64 lo = stream_word(r, src + ci, ci), hi = stream_word(r, src + ci + 8, (i64)ci + 8);
+                v = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
             }
         }
         pf[u] = v;
@@ -1745,7 +1766,11 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__re
             {
                 PROF_T0();
                 stored_copy(r, o, sp, take, lane);
-                mem_sync();                                     // a later block may copy from these bytes
+#if XFG_STORED_SYNC
+                mem_sync();
+#endif
+                // (no wait for the copy's stores: the one reader of earlier output, match resolution,
+                // waits for this wave's stores itself)
                 PROF_ADD(PF_STORED, lane);
             }
             r.bytepos = sp + take;
