@@ -1853,8 +1853,12 @@ __device__ __attribute__((noinline)) u32 draw_chunk(u32 *counter)
     return uni(v);
 }
 
-// Persistent grid: every wave draws chunks from a shared counter until the table is exhausted
-// (n <= 2^30: the counter runs to 3 n).
+// Persistent grid: every wave draws chunks from shared counters until the table is exhausted
+// (n <= 2^30: a counter runs to 3 n and beyond by one per wave).
+#ifndef XFG_DRAW_SLICES
+#define XFG_DRAW_SLICES 32
+#endif
+constexpr int DRAW_SLICES = XFG_DRAW_SLICES;
 #ifndef XFG_WAVES_PER_EU
 #define XFG_WAVES_PER_EU 4            // waves per SIMD the register allocation aims at (the LDS footprint must allow as many)
 #endif
@@ -1877,13 +1881,25 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
     // The counter runs three times over the table: chunks that compress least (the most bits to
     // decode per output byte: the expensive ones) are taken in the first round, the cheapest in the
     // last, so that the grid's last wave finishes on a short chunk.
-    const u32 rounds_n = 3u * n;
-    for (u32 v = draw_chunk(scratch); v < rounds_n; v = draw_chunk(scratch)) {
-        const u32 round = v < n ? 0u : (v < 2u * n ? 1u : 2u);
-        const u32 ci = v - round * n;
-        const u64 cs = uni64(chunks[ci].comp_size), rs = uni64(chunks[ci].raw_size);
-        const u32 cls = cs * 8 >= rs * 5 ? 0u : (cs * 4 >= rs ? 1u : 2u);
-        if (cls == round) inflate_chunk(comp, chunks, ci, raw, res, L, lane);
+    // One counter serves about 10^8 draws a second (they are memory-side atomics on one address); a grid
+    // of cheap chunks (stored blocks) draws faster than that.  So the table is cut into DRAW_SLICES slices
+    // with a counter each, 64 bytes apart; a wave starts on the slice its workgroup index names and moves
+    // on to the next one when a slice is used up, which is also how the grid's tail is shared out.
+    const u32 home = uni(blockIdx.x) % (u32)DRAW_SLICES;
+    for (u32 t = 0; t < (u32)DRAW_SLICES; t++) {
+        const u32 k = (home + t) % (u32)DRAW_SLICES;
+        const u32 lo = (u32)(((u64)n * k) / DRAW_SLICES), hi = (u32)(((u64)n * (k + 1)) / DRAW_SLICES);
+        const u32 m = hi - lo;
+        if (m == 0) continue;
+        u32 *counter = scratch + k * 16u;
+        const u32 rounds_m = 3u * m;
+        for (u32 v = draw_chunk(counter); v < rounds_m; v = draw_chunk(counter)) {
+            const u32 round = v < m ? 0u : (v < 2u * m ? 1u : 2u);
+            const u32 ci = lo + (v - round * m);
+            const u64 cs = uni64(chunks[ci].comp_size), rs = uni64(chunks[ci].raw_size);
+            const u32 cls = cs * 8 >= rs * 5 ? 0u : (cs * 4 >= rs ? 1u : 2u);
+            if (cls == round) inflate_chunk(comp, chunks, ci, raw, res, L, lane);
+        }
     }
 }
 
@@ -1926,7 +1942,7 @@ extern "C" uint32_t xfg_grid_blocks(uint32_t n, int num_cu)
 extern "C" size_t xfg_scratch_bytes(int num_cu)
 {
     (void)num_cu;
-    return 256;                                                 // the token lists live in LDS; nothing is staged in HBM
+    return 64 * xfg::DRAW_SLICES;                               // the chunk counters; the token lists live in LDS, nothing is staged in HBM
 }
 
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,
@@ -1935,7 +1951,7 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunk
 {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = xfg_grid_blocks(n, num_cu);
-    hipError_t e = hipMemsetAsync(d_scratch, 0, 4, stream);      // the chunk counter
+    hipError_t e = hipMemsetAsync(d_scratch, 0, 64 * xfg::DRAW_SLICES, stream);      // the chunk counters
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(xfg::inflate_chunks_kernel, dim3(blocks), dim3(64 * xfg::WAVES_PER_BLOCK), 0, stream,
                        (const uint8_t *)d_comp, (const xfg_chunk *)d_chunks, n,
