@@ -116,7 +116,7 @@ int xfg_decode(xfg_ctx *ctx, const uint8_t *comp, size_t comp_len,
  * pointers (d_comp at least 16-byte aligned), the work is enqueued on
  * `hip_stream` (a hipStream_t; NULL = the context's stream) and the call
  * returns without synchronising.  Allocates nothing per call.  Launches of one context
- * share the context's chunk counter: enqueue them on one stream (or wait in between), never
+ * share the context's chunk counters: enqueue them on one stream (or wait in between), never
  * on two streams that may run them at the same time.  n <= 2^30.  This is what bench.py times.
  */
 int xfg_decode_device(xfg_ctx *ctx, const void *d_comp, size_t comp_len,
