@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("XFG_LIB") or os.path.join(_HERE, "lib", "libxflate_am
 
 # transport codes
 XFG_OK, XFG_E_ARG, XFG_E_HIP, XFG_E_NODEVICE, XFG_E_NOMEM, XFG_E_LIMIT = range(6)
+MAX_CHUNK_COMP, MAX_CHUNK_RAW = (1 << 28) - 64, (1 << 31) - 64      # XFG_MAX_CHUNK_COMP / _RAW
 # per-chunk status
 ST_OK, ST_CORRUPTED, ST_UNEXPECTED_EOF, ST_SIZE_MISMATCH, ST_NO_SYNC, ST_INTERNAL, ST_OUT_FULL = range(7)
 ST_NAMES = ["ok", "corrupted", "unexpected_eof", "size_mismatch", "no_sync", "internal", "out_full"]
@@ -18,7 +19,7 @@ CHUNK_XFLATE_INDEX = CHUNK_END_BLOCK | CHUNK_VERIFY | CHUNK_RFC_REP16
 CHUNK_XFLATE_FOOTER = CHUNK_END_BLOCK | CHUNK_VERIFY | CHUNK_FOOTER | CHUNK_RFC_REP16
 # error classes
 ERR_NONE, ERR_INTERNAL, ERR_INVALID, ERR_DEPRECATED, ERR_CORRUPTED, ERR_CLOSED = range(6)
-ERR_EOF, ERR_UNEXPECTED_EOF, ERR_IO, ERR_DEVICE = 16, 17, 18, 19
+ERR_EOF, ERR_UNEXPECTED_EOF, ERR_IO, ERR_DEVICE, ERR_LIMIT = 16, 17, 18, 19, 20
 REC_UNKNOWN, REC_DEFLATE, REC_INDEX, REC_FOOTER = range(4)
 
 
@@ -184,13 +185,13 @@ class Context:
         check(lib().xfg_deflate_device(self._h, d_raw, raw_len, d_chunks, n, d_comp, comp_len, d_res,
                                        stream or None), "xfg_deflate_device")
 
-    def crc32_device(self, d_raw, d_chunks, n, d_res, d_crc, stream=None):
+    def crc32_device(self, d_raw, raw_len, d_chunks, n, d_res, d_crc, stream=None):
         """xfg_crc32_device (async): CRC-32 of every chunk's decoded bytes into uint32 d_crc[n]; d_res may be 0."""
         f = lib().xfg_crc32_device
         f.restype = ctypes.c_int
-        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                       ctypes.c_void_p, ctypes.c_void_p]
-        check(f(self._h, d_raw, d_chunks, n, d_res or None, d_crc, stream or None), "xfg_crc32_device")
+        check(f(self._h, d_raw, raw_len, d_chunks, n, d_res or None, d_crc, stream or None), "xfg_crc32_device")
 
 
 def crc32_combine(crc_a, crc_b, len_b):

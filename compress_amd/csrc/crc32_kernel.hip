@@ -44,7 +44,7 @@ __host__ __device__ inline u32 xpow8(u64 n) {
 __device__ __forceinline__ u32 uni(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __global__ void __launch_bounds__(64)
-crc32_chunks_kernel(const u8 *__restrict__ raw, const xfg_chunk *__restrict__ chunks, const xfg_result *__restrict__ res,
+crc32_chunks_kernel(const u8 *__restrict__ raw, u64 raw_len, const xfg_chunk *__restrict__ chunks, const xfg_result *__restrict__ res,
                     u32 n, u32 *__restrict__ crc_out)
 {
     __shared__ u32 T[4][256];
@@ -69,6 +69,8 @@ crc32_chunks_kernel(const u8 *__restrict__ raw, const xfg_chunk *__restrict__ ch
         const u64 off = chunks[ci].raw_off;
         u64 len64 = res ? (u64)res[ci].out_produced : chunks[ci].raw_size;
         if (len64 > chunks[ci].raw_size) len64 = chunks[ci].raw_size;
+        // an untrusted table: a chunk beyond the limit or outside the buffer hashes nothing
+        if (len64 > (u64)XFG_MAX_CHUNK_RAW || off > raw_len || len64 > raw_len - off) len64 = 0;
         const u32 len = uni((u32)len64);                        // <= XFG_MAX_CHUNK_RAW < 2^31
         const u8 *p = raw + off;
         // pieces of `piece` bytes (a multiple of 16) that end at the chunk's end: lane l owns
@@ -116,14 +118,14 @@ crc32_chunks_kernel(const u8 *__restrict__ raw, const xfg_chunk *__restrict__ ch
 
 } // namespace xfg_crc
 
-extern "C" hipError_t xfg_launch_crc32(const void *d_raw, const void *d_chunks, const void *d_res, uint32_t n,
+extern "C" hipError_t xfg_launch_crc32(const void *d_raw, size_t raw_len, const void *d_chunks, const void *d_res, uint32_t n,
                                        void *d_crc, int num_cu, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     uint32_t blocks = (uint32_t)num_cu * 16u;
     if (blocks > n) blocks = n;
     hipLaunchKernelGGL(xfg_crc::crc32_chunks_kernel, dim3(blocks), dim3(64), 0, stream,
-                       (const uint8_t *)d_raw, (const xfg_chunk *)d_chunks, (const xfg_result *)d_res, n, (uint32_t *)d_crc);
+                       (const uint8_t *)d_raw, (uint64_t)raw_len, (const xfg_chunk *)d_chunks, (const xfg_result *)d_res, n, (uint32_t *)d_crc);
     return hipGetLastError();
 }
 

@@ -118,8 +118,8 @@ __device__ u32 write_stored(const u8 *src, u32 n, u8 *dst, u32 lane) {
 __device__ __forceinline__ u32 stored_size(u32 n) { return n + 5 * ((n + 65534) / 65535) + 5; }
 
 __global__ void __launch_bounds__(64)
-deflate_chunks_kernel(const u8 *__restrict__ raw, const xfg_chunk *__restrict__ chunks, u32 nchunks,
-                      u8 *__restrict__ comp, xfg_result *__restrict__ res)
+deflate_chunks_kernel(const u8 *__restrict__ raw, u64 raw_len, const xfg_chunk *__restrict__ chunks, u32 nchunks,
+                      u8 *__restrict__ comp, u64 comp_len, xfg_result *__restrict__ res)
 {
     __shared__ WaveLds L;
     const u32 lane = threadIdx.x;
@@ -132,7 +132,13 @@ deflate_chunks_kernel(const u8 *__restrict__ raw, const xfg_chunk *__restrict__ 
         const u32 cap = uni((u32)c.comp_size);                  // bytes this chunk may write
         int status = XFG_ST_OK;
         u32 produced = 0;
-        if (cap < stored_size(n) + 8) {
+        // an untrusted table: sizes beyond the limits, ranges outside the buffers or a misaligned slot are refused
+        const bool bad_desc = c.raw_size > (u64)XFG_MAX_CHUNK_RAW || c.comp_size > (u64)XFG_MAX_CHUNK_COMP ||
+                              c.raw_off > raw_len || c.raw_size > raw_len - c.raw_off ||
+                              c.comp_off > comp_len || c.comp_size > comp_len - c.comp_off || (c.comp_off & 3) != 0;
+        if (bad_desc) {
+            status = XFG_ST_INTERNAL;
+        } else if (cap < stored_size(n) + 8) {
             status = XFG_ST_OUT_FULL;                           // the slot must hold the stored coding at least
         } else {
             for (u32 i = lane; i < (1u << HASH_BITS); i += 64) L.table[i] = NO_POS;
@@ -240,13 +246,13 @@ deflate_chunks_kernel(const u8 *__restrict__ raw, const xfg_chunk *__restrict__ 
 
 } // namespace xfd
 
-extern "C" hipError_t xfg_launch_deflate(const void *d_raw, const void *d_chunks, uint32_t n,
-                                         void *d_comp, void *d_res, int num_cu, hipStream_t stream)
+extern "C" hipError_t xfg_launch_deflate(const void *d_raw, size_t raw_len, const void *d_chunks, uint32_t n,
+                                         void *d_comp, size_t comp_len, void *d_res, int num_cu, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     uint32_t cap = (uint32_t)num_cu * 8u;                       // 16.7 KB of LDS per wave: 8 and some per CU
     uint32_t blocks = n < cap ? n : cap;
     hipLaunchKernelGGL(xfd::deflate_chunks_kernel, dim3(blocks), dim3(64), 0, stream,
-                       (const uint8_t *)d_raw, (const xfg_chunk *)d_chunks, n, (uint8_t *)d_comp, (xfg_result *)d_res);
+                       (const uint8_t *)d_raw, (uint64_t)raw_len, (const xfg_chunk *)d_chunks, n, (uint8_t *)d_comp, (uint64_t)comp_len, (xfg_result *)d_res);
     return hipGetLastError();
 }

@@ -286,17 +286,19 @@ int uvarint(const uint8_t *b, size_t len, uint64_t *out) {
 }
 
 // hash/crc32 ChecksumIEEE
-uint32_t crc32_ieee(const uint8_t *p, size_t n) {
-    static uint32_t table[256];
-    static bool ready = false;
-    if (!ready) {
+struct Crc32Table {
+    uint32_t t[256];
+    Crc32Table() {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i;
             for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
-            table[i] = c;
+            t[i] = c;
         }
-        ready = true;
     }
+};
+uint32_t crc32_ieee(const uint8_t *p, size_t n) {
+    static const Crc32Table tab;                            // function-local static: initialised once, thread-safe (C++11)
+    const uint32_t *table = tab.t;
     uint32_t c = 0xffffffffu;
     for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
     return c ^ 0xffffffffu;
@@ -559,7 +561,7 @@ int xfg_reader::ensure_decoded() {
         const int64_t cs = c.comp_offset - p.comp_offset, rs = c.raw_offset - p.raw_offset;
         if (k > cur_rec && (raw_total + rs > max_window_raw || comp_total + cs > max_window_raw)) break;
         if ((uint64_t)cs > XFG_MAX_CHUNK_COMP || (uint64_t)rs > XFG_MAX_CHUNK_RAW) {
-            if (k == cur_rec) return XFG_ERR_DEVICE;            // documented per-chunk limit of the kernels
+            if (k == cur_rec) return XFG_ERR_LIMIT;             // documented per-chunk limit of the kernels (the reference has none)
             break;
         }
         raw_total += rs; comp_total += cs; last = k;
@@ -766,6 +768,18 @@ extern "C" int xfg_index_parse(const uint8_t *stream, size_t len, xfg_chunk *chu
     *n_out = n;
     if (!chunks) return XFG_ERR_NONE;
     int64_t pc = 0, pr = 0;
+    // the device path's per-chunk limits apply to what this table is for: a stream with a larger chunk is refused here
+    {
+        int64_t qc = 0, qr = 0;
+        for (size_t i = 0; i < n; i++) {
+            const xfg_record &rec = r.idx.records[i];
+            if ((uint64_t)(rec.comp_offset - qc) > XFG_MAX_CHUNK_COMP || (uint64_t)(rec.raw_offset - qr) > XFG_MAX_CHUNK_RAW) {
+                *n_out = 0;
+                return XFG_ERR_LIMIT;
+            }
+            qc = rec.comp_offset; qr = rec.raw_offset;
+        }
+    }
     for (size_t i = 0; i < n && i < cap; i++) {
         const xfg_record &rec = r.idx.records[i];
         memset(&chunks[i], 0, sizeof chunks[i]);

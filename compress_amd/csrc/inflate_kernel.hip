@@ -1704,15 +1704,33 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
 }
 
 // Inflate one chunk; returns through *out.  Everything here is wave-uniform control flow.
-__device__ void inflate_chunk(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 ci,
-                              u8 *__restrict__ raw, xfg_result *__restrict__ res,
+__device__ void inflate_chunk(const u8 *__restrict__ comp, u64 comp_len, const xfg_chunk *__restrict__ chunks, u32 ci,
+                              u8 *__restrict__ raw, u64 raw_len, xfg_result *__restrict__ res,
                               WaveLds &L, u32 lane)
 {
     PROF_T0();
     xfg_chunk c = chunks[ci];
     c.comp_off = uni64(c.comp_off);
     c.raw_off = uni64(c.raw_off);
+    c.comp_size = uni64(c.comp_size);
+    c.raw_size = uni64(c.raw_size);
     const u32 flags = uni(c.flags);
+    // The table may come from an untrusted index (xfg_index_parse) and is never seen by the host on the
+    // device-resident path: a chunk whose sizes exceed the limits, or whose ranges leave the buffers, is
+    // refused here -- nothing read, nothing written.
+    if (c.comp_size > (u64)XFG_MAX_CHUNK_COMP || c.raw_size > (u64)XFG_MAX_CHUNK_RAW ||
+        c.comp_off > comp_len || c.comp_size > comp_len - c.comp_off ||
+        c.raw_off > raw_len || c.raw_size > raw_len - c.raw_off || uni(c.reserved) != 0) {
+        if (lane == 0) {
+            xfg_result out;
+            out.status = XFG_ST_INTERNAL;
+            out.reserved = 0;
+            out.in_consumed = 0;
+            out.out_produced = 0;
+            res[ci] = out;
+        }
+        return;
+    }
 
     Reader r;
     r.comp = comp;
@@ -1863,8 +1881,8 @@ constexpr int DRAW_SLICES = XFG_DRAW_SLICES;
 #define XFG_WAVES_PER_EU 4            // waves per SIMD the register allocation aims at (the LDS footprint must allow as many)
 #endif
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(XFG_WAVES_PER_EU)))
-inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__ chunks, u32 n,
-                      u8 *__restrict__ raw, xfg_result *__restrict__ res,
+inflate_chunks_kernel(const u8 *__restrict__ comp, u64 comp_len, const xfg_chunk *__restrict__ chunks, u32 n,
+                      u8 *__restrict__ raw, u64 raw_len, xfg_result *__restrict__ res,
                       u32 *__restrict__ scratch)
 {
     __shared__ WaveLds lds[WAVES_PER_BLOCK];
@@ -1898,7 +1916,7 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, const xfg_chunk *__restrict__
             const u32 ci = lo + (v - round * m);
             const u64 cs = uni64(chunks[ci].comp_size), rs = uni64(chunks[ci].raw_size);
             const u32 cls = cs * 8 >= rs * 5 ? 0u : (cs * 4 >= rs ? 1u : 2u);
-            if (cls == round) inflate_chunk(comp, chunks, ci, raw, res, L, lane);
+            if (cls == round) inflate_chunk(comp, comp_len, chunks, ci, raw, raw_len, res, L, lane);
         }
     }
 }
@@ -1920,14 +1938,13 @@ extern "C" int xfg_debug_profile(unsigned long long *out, int n)
 
 static int blocks_per_cu()
 {
-    static int cached = 0;
-    if (cached == 0) {
+    static const int cached = [] {                              // initialised once, thread-safe (C++11)
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_kernel, 64 * xfg::WAVES_PER_BLOCK, 0) != hipSuccess || nb < 1)
             nb = 1;
         if (nb > xfg::MAX_BLOCKS_PER_CU) nb = xfg::MAX_BLOCKS_PER_CU;
-        cached = nb;
-    }
+        return nb;
+    }();
     return cached;
 }
 
@@ -1945,8 +1962,8 @@ extern "C" size_t xfg_scratch_bytes(int num_cu)
     return 64 * xfg::DRAW_SLICES;                               // the chunk counters; the token lists live in LDS, nothing is staged in HBM
 }
 
-extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,
-                                         void *d_raw, void *d_res, void *d_scratch,
+extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, const void *d_chunks, uint32_t n,
+                                         void *d_raw, size_t raw_len, void *d_res, void *d_scratch,
                                          int num_cu, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
@@ -1954,7 +1971,7 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunk
     hipError_t e = hipMemsetAsync(d_scratch, 0, 64 * xfg::DRAW_SLICES, stream);      // the chunk counters
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(xfg::inflate_chunks_kernel, dim3(blocks), dim3(64 * xfg::WAVES_PER_BLOCK), 0, stream,
-                       (const uint8_t *)d_comp, (const xfg_chunk *)d_chunks, n,
-                       (uint8_t *)d_raw, (xfg_result *)d_res, (uint32_t *)d_scratch);
+                       (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
+                       (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch);
     return hipGetLastError();
 }

@@ -24,10 +24,24 @@ static int hip_fail(hipError_t e, const char *what) {
 }
 // XFG_TRACE=1 in the environment prints every HIP call of this file to stderr.
 static bool trace_on() {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("XFG_TRACE"); on = (e && *e && *e != '0') ? 1 : 0; }
-    return on == 1;
+    static const bool on = [] { const char *e = getenv("XFG_TRACE"); return e && *e && *e != '0'; }();   // initialised once, thread-safe
+    return on;
 }
+// Every entry point makes its context's device current for the call and puts the caller's device back
+// on every way out (a process that drives several GPUs must not find its current device changed).
+struct DeviceGuard {
+    int prev;
+    bool restore;
+    DeviceGuard() : prev(-1), restore(false) {}
+    hipError_t enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == device) return hipSuccess;
+        const hipError_t e = hipSetDevice(device);
+        restore = e == hipSuccess && prev >= 0;
+        return e;
+    }
+    ~DeviceGuard() { if (restore) (void)hipSetDevice(prev); }
+};
 #define HIP_TRY(expr) do { \
         if (trace_on()) fprintf(stderr, "[xfg] %s\n", #expr); \
         hipError_t e_ = (expr); \
@@ -58,7 +72,7 @@ struct xfg_ctx {
     int device;
     int num_cu;
     hipStream_t stream;
-    void *d_scratch;      // match-token lists of the persistent grid (fixed size, allocated once)
+    void *d_scratch;      // the chunk counters of the persistent grid (xfg_scratch_bytes: 2 KB, allocated once)
     // reusable device staging for the host-pointer path
     void *d_comp; size_t comp_cap;
     void *d_raw; size_t raw_cap;
@@ -83,7 +97,8 @@ extern "C" int xfg_create(int device, xfg_ctx **out) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) { hip_fail(e, "hipGetDeviceCount"); return XFG_E_NODEVICE; }
     if (device < 0 || device >= n) return XFG_E_ARG;
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(device));
     xfg_ctx *c = new (std::nothrow) xfg_ctx();
     if (!c) return XFG_E_NOMEM;
     memset(c, 0, sizeof *c);
@@ -102,7 +117,8 @@ extern "C" int xfg_create(int device, xfg_ctx **out) {
 
 extern "C" void xfg_destroy(xfg_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard;
+    (void)guard.enter(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_comp) (void)hipFree(c->d_comp);
     if (c->d_raw) (void)hipFree(c->d_raw);
@@ -115,11 +131,14 @@ extern "C" void xfg_destroy(xfg_ctx *c) {
 
 extern "C" int xfg_sync(xfg_ctx *c) {
     if (!c) return XFG_E_ARG;
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return XFG_OK;
 }
 
-// The kernel trusts its descriptors: check every one on the host before any launch.
+// The host-pointer entry points check every descriptor before any launch and report XFG_E_LIMIT / XFG_E_ARG;
+// on the device-resident path the same conditions are checked by the kernels, per chunk (XFG_ST_INTERNAL).
 static int check_chunks(const xfg_chunk *chunks, size_t n, size_t comp_len, size_t raw_len) {
     for (size_t i = 0; i < n; i++) {
         const xfg_chunk &c = chunks[i];
@@ -135,16 +154,16 @@ extern "C" int xfg_decode_device(xfg_ctx *c, const void *d_comp, size_t comp_len
                                  const void *d_chunks, size_t n,
                                  void *d_raw, size_t raw_len, void *d_res, void *hip_stream)
 {
-    (void)comp_len; (void)raw_len;
     if (!c) return XFG_E_ARG;
     if (n == 0) return XFG_OK;
     if (!d_comp || !d_chunks || !d_res || (!d_raw && raw_len)) return XFG_E_ARG;
     if (((uintptr_t)d_comp & 15) != 0) return XFG_E_ARG;
     if (n > (1ull << 30)) return XFG_E_ARG;                    // the kernel counts to 3 n in 32 bits
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    // One launch at a time per context: the match-token scratch is per context.
-    HIP_TRY(xfg_launch_inflate(d_comp, d_chunks, (uint32_t)n, d_raw, d_res, c->d_scratch, c->num_cu, s));
+    // One launch at a time per context: the chunk counters are per context.
+    HIP_TRY(xfg_launch_inflate(d_comp, comp_len, d_chunks, (uint32_t)n, d_raw, raw_len, d_res, c->d_scratch, c->num_cu, s));
     return XFG_OK;
 }
 
@@ -156,7 +175,8 @@ extern "C" int xfg_decode(xfg_ctx *c, const uint8_t *comp, size_t comp_len,
     if (n == 0) return XFG_OK;
     int rc = check_chunks(chunks, n, comp_len, raw_len);
     if (rc != XFG_OK) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(c->device));
     if ((rc = grow(&c->d_comp, &c->comp_cap, comp_len + 16)) != XFG_OK) return rc;
     if ((rc = grow(&c->d_raw, &c->raw_cap, raw_len + 16)) != XFG_OK) return rc;
     if ((rc = grow(&c->d_chunks, &c->chunks_cap, n * sizeof(xfg_chunk))) != XFG_OK) return rc;
@@ -185,16 +205,17 @@ extern "C" int xfg_decode(xfg_ctx *c, const uint8_t *comp, size_t comp_len,
     return XFG_OK;
 }
 
-extern "C" int xfg_crc32_device(xfg_ctx *c, const void *d_raw, const void *d_chunks, size_t n,
+extern "C" int xfg_crc32_device(xfg_ctx *c, const void *d_raw, size_t raw_len, const void *d_chunks, size_t n,
                                 const void *d_res, void *d_crc, void *hip_stream)
 {
     if (!c) return XFG_E_ARG;
     if (n == 0) return XFG_OK;
     if (!d_raw || !d_chunks || !d_crc) return XFG_E_ARG;
     if (n > 0xffffffffull) return XFG_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    HIP_TRY(xfg_launch_crc32(d_raw, d_chunks, d_res, (uint32_t)n, d_crc, c->num_cu, s));
+    HIP_TRY(xfg_launch_crc32(d_raw, raw_len, d_chunks, d_res, (uint32_t)n, d_crc, c->num_cu, s));
     return XFG_OK;
 }
 
@@ -209,14 +230,14 @@ extern "C" int xfg_deflate_device(xfg_ctx *c, const void *d_raw, size_t raw_len,
                                   const void *d_chunks, size_t n,
                                   void *d_comp, size_t comp_len, void *d_res, void *hip_stream)
 {
-    (void)raw_len; (void)comp_len;
     if (!c) return XFG_E_ARG;
     if (n == 0) return XFG_OK;
     if (!d_chunks || !d_comp || !d_res || (!d_raw && raw_len)) return XFG_E_ARG;
     if (((uintptr_t)d_comp & 3) != 0 || n > 0xffffffffull) return XFG_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    HIP_TRY(xfg_launch_deflate(d_raw, d_chunks, (uint32_t)n, d_comp, d_res, c->num_cu, s));
+    HIP_TRY(xfg_launch_deflate(d_raw, raw_len, d_chunks, (uint32_t)n, d_comp, comp_len, d_res, c->num_cu, s));
     return XFG_OK;
 }
 
@@ -229,7 +250,8 @@ extern "C" int xfg_deflate(xfg_ctx *c, const uint8_t *raw, size_t raw_len,
     int rc = check_chunks(chunks, n, comp_len, raw_len);        // the same range checks, the other way round
     if (rc != XFG_OK) return rc;
     for (size_t i = 0; i < n; i++) if (chunks[i].comp_off & 3) return XFG_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard;
+    HIP_TRY(guard.enter(c->device));
     if ((rc = grow(&c->d_comp, &c->comp_cap, comp_len + 16)) != XFG_OK) return rc;
     if ((rc = grow(&c->d_raw, &c->raw_cap, raw_len + 16)) != XFG_OK) return rc;
     if ((rc = grow(&c->d_chunks, &c->chunks_cap, n * sizeof(xfg_chunk))) != XFG_OK) return rc;

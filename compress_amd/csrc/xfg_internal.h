@@ -5,13 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-extern "C" hipError_t xfg_launch_inflate(const void *d_comp, const void *d_chunks, uint32_t n,
-                                         void *d_raw, void *d_res, void *d_scratch,
+extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, const void *d_chunks, uint32_t n,
+                                         void *d_raw, size_t raw_len, void *d_res, void *d_scratch,
                                          int num_cu, hipStream_t stream);
 extern "C" size_t xfg_scratch_bytes(int num_cu);
-extern "C" hipError_t xfg_launch_crc32(const void *d_raw, const void *d_chunks, const void *d_res, uint32_t n,
+extern "C" hipError_t xfg_launch_crc32(const void *d_raw, size_t raw_len, const void *d_chunks, const void *d_res, uint32_t n,
                                        void *d_crc, int num_cu, hipStream_t stream);
-extern "C" hipError_t xfg_launch_deflate(const void *d_raw, const void *d_chunks, uint32_t n,
-                                         void *d_comp, void *d_res, int num_cu, hipStream_t stream);
+extern "C" hipError_t xfg_launch_deflate(const void *d_raw, size_t raw_len, const void *d_chunks, uint32_t n,
+                                         void *d_comp, size_t comp_len, void *d_res, int num_cu, hipStream_t stream);
 
 #endif

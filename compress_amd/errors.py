@@ -32,6 +32,11 @@ class DeviceError(RuntimeError):
     """Transport failure below the C ABI (HIP error, missing device, caller I/O error)."""
 
 
+class LimitError(DeviceError):
+    """A chunk (or a plain DEFLATE stream) is larger than the device path decodes in one piece: a limit of this
+    library (include/xflate_amd.h, XFG_MAX_CHUNK_*), not an error of the input; the reference has no such limit."""
+
+
 EOF = EOFError_
 
 

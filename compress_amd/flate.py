@@ -1,7 +1,7 @@
 """flate -- the reference's flate.Reader API (flate/reader.go:14-97) over the GPU inflate kernel.
 
-NewReader(r) takes a bytes-like object or a readable; the whole stream is handed
-to the device as one "chunk" (plain DEFLATE has no
+NewReader(r) takes a bytes-like object or a readable; what has been read of the stream
+is handed to the device as one "chunk" (plain DEFLATE has no
 index, so there is no inter-chunk parallelism here; the per-stream kernels are
 the same).  Semantics follow the in-repo flate package: InputOffset /
 OutputOffset, errors.Corrupted vs io.ErrUnexpectedEOF, all output produced
@@ -21,88 +21,178 @@ _errClosed = errors.Error(errors.Closed, "flate")
 
 
 class Reader(object):
+    """flate.Reader (flate/reader.go:14-33).
+
+    The source may be bytes-like or a readable object.  The "never read more than necessary" contract of
+    compress.ByteReader / compress.BufferedReader (api.go:29-72; canary test flate/flate_test.go:70-92, sync test
+    :124-203) is kept like this, the device being a batch decoder that wants all the input it can get:
+      peekable source (has peek(), the analogue of BufferedReader: io.BufferedReader) -- input is looked at with
+          peek() and consumed with read() only up to InputOffset, so a byte after the final block stays unread;
+      seekable source (seek()/tell(): BytesIO, files) -- read ahead in blocks, then seek back to the byte after
+          the stream (the un-read);
+      any other readable -- read ahead in blocks as the reference's own bufio wrapper does for a plain io.Reader
+          (internal/prefix/reader.go:103-109); no promise about bytes after the stream.
+    Input is pulled only when every decoded byte has been handed out, so a stream that ends in a sync flush is
+    delivered up to the flush without another read of the source (TestSync).  Every pull decodes the stream
+    from its start again (the kernel has no resume state): fine for a few flushes, quadratic for many.
+    """
+    BLOCK = 1 << 20
+
     def __init__(self):
         self.InputOffset = 0      # flate/reader.go:15
         self.OutputOffset = 0     # flate/reader.go:16
-        self._out = b""
-        self._pos = 0
-        self._err = None
-        self._decoded = True
-        self._data = b""
+        self._out = b""           # decoded bytes of the stream so far
+        self._pos = 0             # of which handed out
+        self._err = None          # sticky error (reader.go:59-61)
+        self._status = None       # outcome of the last decode: None = nothing decoded yet
+        self._final_in = 0
+        self._data = bytearray()  # input consumed from the source so far
+        self._src = None
+        self._kind = "bytes"
+        self._start = 0
+        self._src_eof = True
         self._ctx = None
 
     def Reset(self, r, ctx=None):
         """Reset (reader.go:45-56)."""
         self.__init__()
         self._ctx = ctx or default_context()
-        self._data = r.read() if hasattr(r, "read") else bytes(r)
-        self._decoded = False
+        if hasattr(r, "read"):
+            self._src, self._src_eof = r, False
+            if hasattr(r, "peek"):
+                self._kind = "peek"
+            elif hasattr(r, "seek") and hasattr(r, "tell") and (not hasattr(r, "seekable") or r.seekable()):
+                self._kind = "seek"
+                self._start = r.tell()
+            else:
+                self._kind = "plain"
+        else:
+            self._data = bytearray(bytes(r))
 
-    def _decode(self):
+    # ---- input
+    def _pull(self):
+        """More input from the source -> the bytes to decode now (consumed + looked-at), or None at its end."""
+        if self._src_eof:
+            return None
+        if self._kind == "peek":
+            look = bytes(self._src.peek(self.BLOCK))
+            if not look:
+                self._src_eof = True
+                return None
+            self._look = look
+            return bytes(self._data) + look
+        rd = getattr(self._src, "read1", None) or self._src.read
+        blk = rd(self.BLOCK)
+        if not blk:
+            self._src_eof = True
+            return None
+        self._data += blk
+        return bytes(self._data)
+
+    def _settle(self, in_off, finished):
+        """After a decode of consumed + looked-at bytes: consume what the decoder used (peekable source), or give
+        back what it did not (seekable source, once the stream has ended)."""
+        if self._kind == "peek":
+            use = len(self._look) if not finished else max(0, min(len(self._look), in_off - len(self._data)))
+            if use:
+                got = self._src.read(use)
+                self._data += got
+            self._look = b""
+        elif self._kind == "seek" and finished:
+            self._src.seek(self._start + in_off)
+
+    def _decode(self, data):
         L = capi.lib()
-        data = self._data
-        cap = max(4096, 4 * len(data))
+        cap = max(4096, 4 * len(data), 2 * len(self._out))
         while True:
             out = ctypes.create_string_buffer(cap)
             i, o, e = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
             rc = L.xfg_flate_decode(self._ctx.handle, data, len(data), out, cap,
                                     ctypes.byref(i), ctypes.byref(o), ctypes.byref(e))
             if rc == capi.XFG_E_NOMEM and cap < (len(data) + 8) * 1100:
-                cap *= 4
+                cap *= 4                                   # DEFLATE expands at most 1032-fold: at most five rounds
                 continue
+            if rc == capi.XFG_E_LIMIT:
+                raise errors.LimitError("a plain DEFLATE stream of more than %d compressed bytes is beyond the device "
+                                        "path's single-chunk limit" % capi.MAX_CHUNK_COMP)
             capi.check(rc, "xfg_flate_decode")
             break
         self._out = out.raw[:o.value]
         self._final_in = i.value
-        if e.value == capi.ERR_NONE:
-            self._final_err = errors.EOF()
-        elif e.value == capi.ERR_CORRUPTED:
-            self._final_err = errors.Error(errors.Corrupted, "flate")
-        elif e.value == capi.ERR_UNEXPECTED_EOF:
-            self._final_err = errors.UnexpectedEOF()
-        else:
-            self._final_err = errors.Error(errors.Internal, "flate")
-        self._decoded = True
+        self._status = e.value
+
+    def _final_error(self):
+        if self._status == capi.ERR_NONE:
+            return errors.EOF()
+        if self._status == capi.ERR_CORRUPTED:
+            return errors.Error(errors.Corrupted, "flate")
+        if self._status == capi.ERR_UNEXPECTED_EOF:
+            return errors.UnexpectedEOF()
+        return errors.Error(errors.Internal, "flate")
+
+    def _advance(self):
+        """Decode more.  Returns False when the stream's outcome is final (self._err is set)."""
+        while True:
+            if self._status is None and self._kind == "bytes":
+                self._decode(bytes(self._data))
+                data_all = True
+            else:
+                data = self._pull()
+                if data is None:
+                    if self._status is None:               # an empty source
+                        self._decode(b"")
+                    data_all = True
+                else:
+                    had = len(self._out)
+                    self._decode(data)
+                    data_all = False
+                    finished = self._status != capi.ERR_UNEXPECTED_EOF
+                    self._settle(self._final_in, finished)
+                    if not finished:
+                        if len(self._out) > had:
+                            return True                    # new output: hand it out before asking for more input
+                        continue
+            if self._status != capi.ERR_UNEXPECTED_EOF or data_all:
+                self.InputOffset = self._final_in
+                self._err = self._final_error()
+                return False
 
     def Read(self, n=-1):
         """Read (reader.go:58-88).  n < 0: ReadAll -> bytes (clean EOF) or raises after keeping
         the partial output in .partial."""
-        if self._err is not None and self._pos >= len(self._out):
-            raise self._err
-        if not self._decoded:
-            self._decode()
         if n is None or n < 0:
+            while self._err is None and self._advance():
+                pass
             data = self._out[self._pos:]
             self._pos = len(self._out)
             self.OutputOffset += len(data)
-            self.InputOffset = self._final_in
-            self._err = self._final_err
             if isinstance(self._err, errors.EOF):
                 return data
             self.partial = data
             raise self._err
-        if self._pos < len(self._out):
-            data = self._out[self._pos:self._pos + n]
-            self._pos += len(data)
-            self.OutputOffset += len(data)
-            if self._pos >= len(self._out):
-                self.InputOffset = self._final_in
-            return data
-        self.InputOffset = self._final_in
-        self._err = self._final_err
-        raise self._err
+        while True:
+            if self._pos < len(self._out):
+                data = self._out[self._pos:self._pos + n]
+                self._pos += len(data)
+                self.OutputOffset += len(data)
+                if self._pos >= len(self._out) and self._err is not None:
+                    self.InputOffset = self._final_in
+                return data
+            if self._err is not None:
+                raise self._err
+            self._advance()
 
     read = Read
 
     def Close(self):
-        """Close (reader.go:90-97)."""
-        self._out, self._pos = b"", 0
-        if self._err is None and not self._decoded:
-            return                     # nothing read yet: the reference returns zr.err == nil
-        if self._err is None or isinstance(self._err, errors.EOF) or errors.IsClosed(self._err):
+        """Close (reader.go:90-97): io.EOF and errClosed become errClosed and nil is returned; any other sticky
+        error is returned (raised); what was decoded and not yet read is dropped."""
+        self._pos = len(self._out)
+        if isinstance(self._err, errors.EOF) or errors.IsClosed(self._err):
             self._err = _errClosed
             return
-        raise self._err
+        if self._err is not None:
+            raise self._err
 
 
 def NewReader(r, conf=None, ctx=None):

@@ -49,6 +49,8 @@ def _raise_class(cls):
         raise _errorf(cls)
     if cls == capi.ERR_IO:
         raise errors.DeviceError("read/seek callback failed")
+    if cls == capi.ERR_LIMIT:
+        raise errors.LimitError("a chunk exceeds the device path's per-chunk size limit (XFG_MAX_CHUNK_COMP / XFG_MAX_CHUNK_RAW)")
     raise errors.DeviceError("device/transport failure: %s" % capi.lib().xfg_last_error().decode())
 
 

@@ -68,6 +68,10 @@ extern "C" {
 #define XFG_CHUNK_XFLATE_INDEX   (XFG_CHUNK_END_BLOCK | XFG_CHUNK_VERIFY | XFG_CHUNK_RFC_REP16)
 #define XFG_CHUNK_XFLATE_FOOTER  (XFG_CHUNK_END_BLOCK | XFG_CHUNK_VERIFY | XFG_CHUNK_FOOTER | XFG_CHUNK_RFC_REP16)
 
+/* Per-chunk size limits of the device path (32-bit bit positions inside a chunk).  The reference has
+ * none: a chunk (or, for xfg_flate_decode, a whole plain DEFLATE stream) beyond them is reported as
+ * XFG_E_LIMIT by the batch calls and as XFG_ERR_LIMIT by the Reader and by xfg_index_parse;
+ * no fixture of the reference reaches these sizes, so behaviour there is unpinned. */
 #define XFG_MAX_CHUNK_COMP ((1u << 28) - 64)   /* bytes of compressed data per chunk   */
 #define XFG_MAX_CHUNK_RAW  ((1u << 31) - 64)   /* bytes of decompressed data per chunk */
 
@@ -118,6 +122,16 @@ int xfg_decode(xfg_ctx *ctx, const uint8_t *comp, size_t comp_len,
  * returns without synchronising.  Allocates nothing per call.  Launches of one context
  * share the context's chunk counters: enqueue them on one stream (or wait in between), never
  * on two streams that may run them at the same time.  n <= 2^30.  This is what bench.py times.
+ *
+ * Trust: the chunk table lives on the device and the host never sees it, so it is NOT trusted.  The
+ * kernel checks every descriptor against comp_len / raw_len and the per-chunk limits before it touches
+ * the chunk: comp_size > XFG_MAX_CHUNK_COMP, raw_size > XFG_MAX_CHUNK_RAW, a range that leaves
+ * [0, comp_len) / [0, raw_len), or reserved != 0 gives that chunk status XFG_ST_INTERNAL with
+ * in_consumed = out_produced = 0; nothing is read or written for it (what xfg_decode reports as
+ * XFG_E_LIMIT / XFG_E_ARG for the whole call).  Overlapping output ranges of two chunks are the
+ * caller's business, as in xfg_decode.  xfg_deflate_device and xfg_crc32_device check the same way
+ * (a refused chunk compresses / hashes nothing).  The call leaves the calling thread's current HIP
+ * device as it found it.
  */
 int xfg_decode_device(xfg_ctx *ctx, const void *d_comp, size_t comp_len,
                       const void *d_chunks, size_t n,
@@ -128,9 +142,10 @@ int xfg_decode_device(xfg_ctx *ctx, const void *d_comp, size_t comp_len,
  * reference's gzip embedding hashes on the CPU while writing (xflate/example_test.go:171-182),
  * a GPU reader checks the trailer with this.  Device pointers, asynchronous like
  * xfg_decode_device.  d_crc[i] = crc32(raw[raw_off_i .. raw_off_i + out_produced_i)); d_res may
- * be NULL (then every chunk counts raw_size bytes).
+ * be NULL (then every chunk counts raw_size bytes).  raw_len = bytes at d_raw: a chunk whose range
+ * leaves it hashes nothing (d_crc[i] = 0).
  */
-int xfg_crc32_device(xfg_ctx *ctx, const void *d_raw, const void *d_chunks, size_t n,
+int xfg_crc32_device(xfg_ctx *ctx, const void *d_raw, size_t raw_len, const void *d_chunks, size_t n,
                      const void *d_res, void *d_crc /* uint32_t[n] */, void *hip_stream);
 /* crc32(A || B) from crc32(A), crc32(B), len(B): folds the per-chunk values into the stream's. Host only. */
 uint32_t xfg_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
@@ -176,6 +191,9 @@ int xfg_deflate_device(xfg_ctx *ctx, const void *d_raw, size_t raw_len,
 #define XFG_ERR_UNEXPECTED_EOF  17   /* io.ErrUnexpectedEOF */
 #define XFG_ERR_IO              18   /* the caller's read/seek callback failed */
 #define XFG_ERR_DEVICE          19   /* transport failure (see xfg_last_error) */
+#define XFG_ERR_LIMIT           20   /* a chunk exceeds XFG_MAX_CHUNK_COMP / XFG_MAX_CHUNK_RAW: a limit of this
+                                        library's device path that the reference does not have (it reads such
+                                        a stream); not a property of the input */
 
 /* io.ReadSeeker supplied by the caller (xflate.NewReader's rs argument).
  * read: up to n bytes into buf, returns bytes read, 0 at EOF, <0 on error.

@@ -53,7 +53,7 @@ def _gpu_crc32(ctx, stream, raw_len):
     d_crc = torch.zeros(n, dtype=torch.int32, device=dev)
     s = torch.cuda.current_stream(dev).cuda_stream
     ctx.decode_device(d_comp.data_ptr(), len(stream), d_chunks.data_ptr(), n, d_raw.data_ptr(), raw_len, d_res.data_ptr(), s)
-    ctx.crc32_device(d_raw.data_ptr(), d_chunks.data_ptr(), n, d_res.data_ptr(), d_crc.data_ptr(), s)
+    ctx.crc32_device(d_raw.data_ptr(), d_raw.numel(), d_chunks.data_ptr(), n, d_res.data_ptr(), d_crc.data_ptr(), s)
     torch.cuda.synchronize(dev)
     res = d_res.cpu().numpy().view("i4,u4,i8,i8")
     assert (res["f0"] == 0).all()
@@ -151,7 +151,7 @@ def test_crc32_ragged_chunks(ctx):
     d_raw = torch.from_numpy(data).to(dev)
     d_chunks = torch.frombuffer(bytearray(bytes((capi.Chunk * n)(*descs))), dtype=torch.uint8).to(dev)
     d_crc = torch.zeros(n, dtype=torch.int32, device=dev)
-    ctx.crc32_device(d_raw.data_ptr(), d_chunks.data_ptr(), n, 0, d_crc.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    ctx.crc32_device(d_raw.data_ptr(), d_raw.numel(), d_chunks.data_ptr(), n, 0, d_crc.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
     got = d_crc.cpu().numpy().view("u4")
     host = data.tobytes()

@@ -26,11 +26,11 @@ for w in sys.argv[1:] or ["c2"]:
     s = stream.cuda_stream
     ctx.decode_device(d_comp.data_ptr(), len(shard["comp"]), d_chunks.data_ptr(), n, d_raw.data_ptr(), shard["raw_len"], d_res.data_ptr(), s)
     for _ in range(2):
-        ctx.crc32_device(d_raw.data_ptr(), d_chunks.data_ptr(), n, d_res.data_ptr(), d_crc.data_ptr(), s)
+        ctx.crc32_device(d_raw.data_ptr(), d_raw.numel(), d_chunks.data_ptr(), n, d_res.data_ptr(), d_crc.data_ptr(), s)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(stream)
     for _ in range(5):
-        ctx.crc32_device(d_raw.data_ptr(), d_chunks.data_ptr(), n, d_res.data_ptr(), d_crc.data_ptr(), s)
+        ctx.crc32_device(d_raw.data_ptr(), d_raw.numel(), d_chunks.data_ptr(), n, d_res.data_ptr(), d_crc.data_ptr(), s)
     b.record(stream)
     torch.cuda.synchronize(dev)
     ms = a.elapsed_time(b) / 5
