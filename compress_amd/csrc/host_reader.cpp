@@ -794,6 +794,72 @@ extern "C" int xfg_index_parse(const uint8_t *stream, size_t len, xfg_chunk *chu
     return XFG_ERR_NONE;
 }
 
+// ------------------------------------------------------------ test hooks ---
+// include/xflate_amd_testhooks.h: the reference's unit-test vectors for meta.Reader and index reach the
+// C++ above through these, not through whole streams.
+#include "../../include/xflate_amd_testhooks.h"
+
+extern "C" int xfg_test_meta_block(const uint8_t *in, size_t len, uint8_t *out, size_t *out_len, int *final, int64_t *in_off) {
+    meta::Reader mr;
+    mr.reset(in, len);
+    const int e = mr.decode_block();
+    if (out && out_len) { memcpy(out, mr.buf.data(), mr.buf.size()); *out_len = mr.buf.size(); }
+    if (final) *final = mr.final;
+    if (in_off) *in_off = mr.input_offset;
+    return e;
+}
+
+extern "C" int xfg_test_meta_stream(const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len,
+                                    int64_t *in_off, int64_t *out_off, int64_t *num_blocks, int *final_mode) {
+    meta::Reader mr;
+    mr.reset(in, len);
+    Bytes bw;
+    const int e = mr.read_all(bw);
+    if (mr.err == XFG_ERR_NONE || mr.err == XFG_ERR_EOF) mr.final_mode = mr.final;   // Close, meta/reader.go:101-113
+    if (out_len) *out_len = bw.size();
+    if (out && bw.size() <= out_cap) memcpy(out, bw.data(), bw.size());
+    if (in_off) *in_off = mr.input_offset;
+    if (out_off) *out_off = mr.output_offset;
+    if (num_blocks) *num_blocks = mr.num_blocks;
+    if (final_mode) *final_mode = mr.final_mode;
+    return e;
+}
+
+extern "C" int xfg_test_meta_reverse_search(const uint8_t *data, size_t len) { return meta::reverse_search(data, len); }
+
+extern "C" void *xfg_test_index_new(void) { return new (std::nothrow) Index(); }
+extern "C" void xfg_test_index_free(void *idx) { delete (Index *)idx; }
+extern "C" int xfg_test_index_append_record(void *idx, int64_t comp_size, int64_t raw_size, int type) {
+    return ((Index *)idx)->append_record(comp_size, raw_size, type) ? 1 : 0;
+}
+extern "C" int xfg_test_index_append_index(void *idx, const void *other) {
+    return ((Index *)idx)->append_index(*(const Index *)other) ? 1 : 0;
+}
+extern "C" void xfg_test_index_push_raw(void *idx, int64_t comp_offset, int64_t raw_offset, int type) {
+    xfg_record rec; memset(&rec, 0, sizeof rec);
+    rec.comp_offset = comp_offset; rec.raw_offset = raw_offset; rec.type = type;
+    ((Index *)idx)->records.push_back(rec);
+}
+extern "C" int64_t xfg_test_index_len(const void *idx) { return (int64_t)((const Index *)idx)->records.size(); }
+extern "C" void xfg_test_index_record(const void *idx, int64_t i, xfg_record *out) { *out = ((const Index *)idx)->records[(size_t)i]; }
+extern "C" void xfg_test_index_last_record(const void *idx, xfg_record *out) { *out = ((const Index *)idx)->last_record(); }
+extern "C" int64_t xfg_test_index_search(const void *idx, int64_t offset) { return ((const Index *)idx)->search(offset); }
+extern "C" void xfg_test_index_get_records(const void *idx, int64_t i, xfg_record *prev, xfg_record *curr) {
+    ((const Index *)idx)->get_records(i, prev, curr);
+}
+extern "C" int xfg_test_decode_index(const uint8_t *enc, size_t len, void *idx, int64_t *back_size) {
+    MemSrc src = { enc, (int64_t)len, 0 };
+    xfg_reader r;
+    r.ctx = nullptr;
+    r.rd_fn = mem_read; r.sk_fn = mem_seek; r.user = &src;
+    r.bytes_read = 0;
+    Index *ix = (Index *)idx;
+    ix->index_size = (int64_t)len;
+    const int e = r.decode_index(ix);
+    if (back_size) *back_size = ix->back_size;
+    return e;
+}
+
 // Index-range sharding: cut the chunk table into n_shards contiguous
 // record ranges of about equal work, work = comp_size + raw_size (the bytes a GPU reads and
 // writes for the chunk).  Shard k owns records [first[k], first[k+1]).  Records are never

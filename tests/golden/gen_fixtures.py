@@ -18,7 +18,8 @@ Sources (all under /root/reference):
   xflate/internal/meta/reader_test.go:38-431  -> meta_reader.json
   xflate/internal/meta/reader_test.go:480-582 -> meta_reader.json ("streams")
   xflate/writer_test.go:25-112                -> xflate_writer.json
-  xflate/index_test.go                        -> (restated by hand in tests/test_index.py)
+  xflate/index_test.go                        -> index_tables.json (the tables transcribed as data, by hand: three Go struct
+                                                 literals; tests/test_index.py and tests/test_host_cpp_vectors.py read them)
   internal/testutil/bitgen_test.go:14-237     -> bitgen.json
   internal/prefix/prefix_test.go (fixed DEFLATE code sets) -> checked in tests by RFC 1951 tables
   testdata/*.{txt,bin}                        -> sha256 + sizes in corpora.json;

@@ -55,3 +55,34 @@ def test_search_and_get_records():
     assert prev == (7, 10, 1) and curr[2] == xo.UNKNOWN_TYPE
     prev, curr = idx.get_records(-1)
     assert prev == (0, 0, 0) and curr[2] == xo.UNKNOWN_TYPE
+
+
+# ---- the reference's own tables (xflate/index_test.go:57-184), from tests/golden/index_tables.json
+def _literal(records):
+    idx = xo.Index()
+    idx.records = [tuple(r) for r in records]
+    return idx
+
+
+def test_reference_tables_append():
+    from conftest import load_golden
+    T = load_golden("index_tables.json")
+    idx = xo.Index()
+    assert tuple(idx.last_record()) == (0, 0, 0)
+    for c, r, ok in T["append_records"]:
+        assert idx.append_record(c, r, 0) == ok
+    assert list(idx.last_record()) == T["last_after_records"]
+    for v in T["append_indexes"]:
+        assert idx.append_index(_literal(v["records"])) == v["ok"]
+    assert list(idx.last_record()) == T["last_after_indexes"]
+    assert [list(r) for r in idx.records] == T["final"]
+
+
+def test_reference_tables_search():
+    from conftest import load_golden
+    T = load_golden("index_tables.json")
+    for v in T["search"]:
+        idx = _literal(v["records"])
+        for off, prev, curr in v["queries"]:
+            p, c = idx.get_records(idx.search(off))
+            assert list(p) == prev and list(c) == curr, (v["records"], off)
