@@ -4,12 +4,20 @@
   python bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path (xfg_decode_device: the inflate kernels) over this
-rank's shard of a synthetic XFLATE stream that is already resident in HBM.  The
-workload is BASELINE.json configs[1]: 1 GiB of raw data per GPU in 64 KiB chunks,
-round-robin huffman / repeats / digits generators, zlib level 6, one sync flush per
-chunk, 4096 records per index.  With N ranks the stream is N GiB and rank k owns the
-index records [k*16384, (k+1)*16384) (index-range sharding; no data-path collective),
-so per-GPU work is fixed: "scaling": "weak".
+rank's shard of a synthetic XFLATE stream that is already resident in HBM.
+
+  N = 1   BASELINE.json configs[1] ("c2"): 1 GiB of raw data in 16 384 chunks of 64 KiB,
+          round-robin huffman / repeats / digits generators, zlib level 6, one sync flush
+          per chunk.
+  N > 1   BASELINE.json configs[2] ("c3_stream"): ONE 32 GiB stream of 131 072 chunks of
+          256 KiB with its 32 indexes (4096 records each) and footer.  Every rank parses the
+          index with xfg_index_parse, cuts the record table with xfg_shard_plan and decodes
+          the records [first[k], first[k+1]) of its rank -- index and footer records included,
+          as xflate.Reader does -- from its own device buffers: index-range sharding, no
+          data-path collective.  The total work is fixed: "scaling": "strong".  The stream's
+          chunk bytes are 384 distinct chunks tiled (chunks are independent, so a tiling with
+          a fresh index is a valid stream); only the indexes and the footer exist on the host
+          (a sparse file), each rank's compressed range is put together on its device.
 
 Rank 0 prints ONE JSON line with the metric plus
   roofline     achieved = (sum csize + sum rsize) per launch / mean kernel time (HIP events
@@ -45,6 +53,9 @@ WORKLOADS = {
     "c2": (16384, 65536, ("huffman", "repeats", "digits"), 6, 768),
     "c3": (16384, 262144, ("huffman", "repeats", "digits"), 6, 384),     # 4 GiB per GPU, 256 KiB chunks
     "small": (768, 65536, ("huffman", "repeats", "digits"), 6, 96),
+    # BASELINE configs[2]: the whole 32 GiB stream (chunk count is the STREAM's, shared out over the ranks by xfg_shard_plan)
+    "c3_stream": (131072, 262144, ("huffman", "repeats", "digits"), 6, 384),
+    "c3_stream_small": (8192, 262144, ("huffman", "repeats", "digits"), 6, 96),   # the same path at 2 GiB (rehearsals, tests)
     "c2x4": (65536, 65536, ("huffman", "repeats", "digits"), 6, 768),    # diagnostic: how much of c2's time is the grid's tail
 
     # single-kind diagnostics (not bench lines): where does the time go per data shape
@@ -64,12 +75,11 @@ WORKLOADS = {
 }
 
 
-def build_shard(name, rank):
-    """-> dict(stream bytes of this rank's chunks (deflate records only), descriptors, distinct raws)."""
+def make_distinct(name):
+    """The workload's distinct chunks: [(raw, compressed)...]."""
     import zlib
-    from compress_amd import capi, synth
+    from compress_amd import synth
     n_chunks, chunk_size, kinds, level, nd = WORKLOADS[name]
-    first = rank * n_chunks                       # global index of this rank's first record
 
     def make(j):
         kind = kinds[j % len(kinds)]
@@ -87,7 +97,92 @@ def build_shard(name, rank):
         return raw, synth.deflate_chunk(raw, level, zlib.Z_DEFAULT_STRATEGY)
 
     with ThreadPoolExecutor(16) as ex:
-        made = list(ex.map(make, range(nd)))
+        return list(ex.map(make, range(nd)))
+
+
+def build_stream_shard(name, rank, world, dev):
+    """BASELINE configs[2].  The stream exists as a sparse file (indexes and footer at their offsets, holes where
+    the tiled chunks go); xfg_index_parse reads it through an mmap, xfg_shard_plan cuts the record table, and this
+    rank's compressed byte range is put together on the device from the distinct chunks.
+    -> dict like build_shard's, with the device tensors already made."""
+    import mmap
+    import tempfile
+    import numpy as np
+    import torch
+    from compress_amd import capi, synth
+    n_chunks, chunk_size, kinds, level, nd = WORKLOADS[name]
+    made = make_distinct(name)
+    csz = [len(m[1]) for m in made]
+    total_len, blobs = synth.assemble_sparse([csz[i % nd] for i in range(n_chunks)], [chunk_size] * n_chunks)
+    with tempfile.TemporaryFile(dir=os.environ.get("TMPDIR") or "/tmp") as f:
+        f.truncate(total_len)
+        for off, b in blobs:
+            f.seek(off)
+            f.write(b)
+        f.flush()
+        mm = mmap.mmap(f.fileno(), total_len, prot=mmap.PROT_READ)
+        view = np.frombuffer(mm, dtype=np.uint8)
+        ptr = ctypes.c_void_p(view.ctypes.data)
+        L = capi.lib()
+        nrec = ctypes.c_size_t()
+        err = L.xfg_index_parse(ptr, total_len, None, 0, ctypes.byref(nrec))
+        if err != capi.ERR_NONE:
+            raise SystemExit("xfg_index_parse failed: class %d" % err)
+        table = (capi.Chunk * nrec.value)()
+        err = L.xfg_index_parse(ptr, total_len, table, nrec.value, ctypes.byref(nrec))
+        if err != capi.ERR_NONE:
+            raise SystemExit("xfg_index_parse failed: class %d" % err)
+        del view
+        mm.close()
+    first = (ctypes.c_size_t * (world + 1))()
+    capi.check(L.xfg_shard_plan(table, nrec.value, world, first), "xfg_shard_plan")
+    lo, hi = first[rank], first[rank + 1]
+    n = hi - lo
+    comp_lo = table[lo].comp_off if n else 0
+    comp_hi = table[hi - 1].comp_off + table[hi - 1].comp_size if n else 0
+    raw_lo = table[lo].raw_off if n else 0
+    raw_hi = table[hi - 1].raw_off + table[hi - 1].raw_size if n else 0
+    comp_len, raw_len = comp_hi - comp_lo, raw_hi - raw_lo
+    # this rank's descriptors, relative to its own buffers
+    descs = (capi.Chunk * max(n, 1))()
+    for i in range(n):
+        c = table[lo + i]
+        descs[i] = capi.Chunk(c.comp_off - comp_lo, c.comp_size, c.raw_off - raw_lo, c.raw_size, c.flags, 0)
+    # the compressed range on the device: distinct chunks tiled, index / footer blobs in between
+    d_distinct = torch.frombuffer(bytearray(b"".join(m[1] for m in made)), dtype=torch.uint8).to(dev)
+    dstart = np.concatenate([[0], np.cumsum(csz)])
+    d_comp = torch.zeros(comp_len + 64, dtype=torch.uint8, device=dev)
+    blob_at = dict(blobs)
+    n_deflate = 0
+    deflate_first = None                                        # stream-wide ordinal of this rank's first deflate record
+    ordinal = sum(1 for i in range(lo) if table[i].flags & capi.CHUNK_SYNC)
+    for i in range(n):
+        c = table[lo + i]
+        dst = c.comp_off - comp_lo
+        if c.flags & capi.CHUNK_SYNC:                           # a deflate record: the tiled chunk
+            if deflate_first is None:
+                deflate_first = ordinal
+            k = (ordinal + n_deflate) % nd
+            assert c.comp_size == csz[k]
+            d_comp[dst:dst + c.comp_size] = d_distinct[int(dstart[k]):int(dstart[k + 1])]
+            n_deflate += 1
+        else:                                                   # an index or the footer: its own bytes
+            b = blob_at[c.comp_off]
+            assert len(b) == c.comp_size
+            d_comp[dst:dst + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    del d_distinct
+    return {"descs": descs, "n": n, "chunk_size": chunk_size, "made": made, "first": deflate_first or 0, "nd": nd,
+            "raw_len": raw_len, "comp_len": comp_len, "d_comp": d_comp, "n_deflate": n_deflate,
+            "stream": {"records": nrec.value, "bytes": total_len, "raw_bytes": n_chunks * chunk_size,
+                       "indexes": len(blobs) - 1, "rank_records": [int(first[k + 1] - first[k]) for k in range(world)]}}
+
+
+def build_shard(name, rank):
+    """-> dict(stream bytes of this rank's chunks (deflate records only), descriptors, distinct raws)."""
+    from compress_amd import capi
+    n_chunks, chunk_size, kinds, level, nd = WORKLOADS[name]
+    first = rank * n_chunks                       # global index of this rank's first record
+    made = make_distinct(name)
     comp = bytearray()
     descs = (capi.Chunk * n_chunks)()
     for i in range(n_chunks):
@@ -148,12 +243,28 @@ def zlib_baseline(shard, threads):
     return time.perf_counter() - t0, bad
 
 
+def go_baseline_note():
+    """the reference Go reader, goroutine-parallel, is the baseline north_star names; it needs a Go
+    toolchain and the reference module, neither of which exists on the box.  Say so, never substitute silently."""
+    import shutil
+    import subprocess
+    exe = shutil.which("go")
+    if not exe:
+        return "unavailable (no toolchain: `go` is not on PATH)"
+    try:
+        ver = subprocess.run([exe, "version"], capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception as e:                                     # noqa: BLE001
+        return "unavailable (`go version` failed: %s)" % e
+    return "toolchain present (%s) but the reference module is not on this box: not run" % ver
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 on one GPU (BASELINE configs[1]), c3_stream on several (configs[2])")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -184,12 +295,21 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    shard = build_shard(args.workload, rank)
-    n = shard["n"]
-    comp_len, raw_len = len(shard["comp"]), shard["raw_len"]
+    if args.workload is None:
+        args.workload = "c2" if world == 1 else "c3_stream"
+    is_stream = args.workload.startswith("c3_stream")
+    if is_stream:
+        shard = build_stream_shard(args.workload, rank, world, dev)
+        n = shard["n"]
+        comp_len, raw_len = shard["comp_len"], shard["raw_len"]
+        d_comp = shard["d_comp"]
+    else:
+        shard = build_shard(args.workload, rank)
+        n = shard["n"]
+        comp_len, raw_len = len(shard["comp"]), shard["raw_len"]
+        d_comp = torch.frombuffer(bytearray(shard["comp"]) + bytearray(64), dtype=torch.uint8).to(dev)
 
     ctx = capi.Context(local_rank)
-    d_comp = torch.frombuffer(bytearray(shard["comp"]) + bytearray(64), dtype=torch.uint8).to(dev)
     d_chunks = torch.frombuffer(bytearray(bytes(shard["descs"])), dtype=torch.uint8).to(dev)
     d_raw = torch.zeros(raw_len + 64, dtype=torch.uint8, device=dev)
     d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
@@ -215,14 +335,18 @@ def main():
     # parity gate (untimed): every chunk ok, sizes as promised, bytes equal to the generator's raw data
     verified = None
     if not args.no_verify:
+        import numpy as np
         res = d_res.cpu().numpy().view("i4,u4,i8,i8")
-        ok = bool((res["f0"] == 0).all()) and bool((res["f3"] == shard["chunk_size"]).all())
+        want_out = np.array([shard["descs"][i].raw_size for i in range(n)], dtype=np.int64)
+        ok = bool((res["f0"] == 0).all()) and bool((res["f3"] == want_out).all())
         nd, cs = shard["nd"], shard["chunk_size"]
         distinct = torch.frombuffer(bytearray(b"".join(m[0] for m in shard["made"])), dtype=torch.uint8).to(dev).view(nd, cs)
-        idx = (torch.arange(n, device=dev) + shard["first"]) % nd
-        got = d_raw[:raw_len].view(n, cs)
+        nv = shard.get("n_deflate", n)                        # records that produce output (index and footer records produce none)
+        ok = ok and nv * cs == raw_len
+        idx = (torch.arange(nv, device=dev) + shard["first"]) % nd
+        got = d_raw[:raw_len].view(nv, cs)
         eq = True
-        for lo in range(0, n, 2048):                          # bounded temporaries
+        for lo in range(0, nv, 2048):                         # bounded temporaries
             eq = eq and bool(torch.equal(got[lo:lo + 2048], distinct[idx[lo:lo + 2048]]))
         verified = ok and eq
         del distinct
@@ -241,17 +365,23 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / max(args.steps, 1)
 
+    sum_raw, sum_comp = float(raw_len), float(comp_len)
     if dist is not None:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
+        t = torch.tensor([sum_raw, sum_comp], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        sum_raw, sum_comp = float(t[0]), float(t[1])
 
     out = None
     if rank == 0:
-        total_raw = raw_len * world * args.steps
+        total_raw = sum_raw * args.steps                     # what all ranks decoded
         value = total_raw / elapsed / 1e9
-        algo_bytes = comp_len + raw_len                      # per launch, this rank (every rank has the same shape)
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        algo_bytes = int(sum_comp + sum_raw)                 # per launch, all ranks: compressed bytes read + raw bytes written
+        # the dominant kernel's roofline, per GPU: this node's algorithmic bytes over the slowest rank's mean launch time,
+        # against n_gpus x 8 TB/s
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 / world
         n_chunks, chunk_size, kinds, level, nd = WORKLOADS[args.workload]
         out = {
             "metric": "decompressed GB/s (node), xflate decode",
@@ -262,24 +392,41 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if is_stream else "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": ("REHEARSAL, all ranks on one device; " if rehearsal else "") + "synthetic (%d distinct chunks per kind-mix tiled to %d chunks per GPU; seeds in compress_amd/synth.py)" % (nd, n_chunks),
-            "config": {"workload": "%s: %d x %d KiB chunks per GPU (%s), zlib level %d, sync flush per chunk; "
-                                   "index-range sharded over %d GPU(s)" % (args.workload, n_chunks, chunk_size >> 10,
-                                                                          "/".join(kinds), level, world),
-                       "raw_bytes_per_gpu": raw_len, "comp_bytes_per_gpu": comp_len,
-                       "ratio": round(raw_len / comp_len, 3), "verified_bit_exact": verified},
+            "data": ("REHEARSAL, all ranks on one device; " if rehearsal else "") + "synthetic (%d distinct chunks per kind-mix tiled to %d chunks per %s; seeds in compress_amd/synth.py)" % (nd, n_chunks, "stream" if is_stream else "GPU"),
+            "config": ({"workload": "%s: ONE %.0f GiB XFLATE stream, %d x %d KiB chunks (%s), zlib level %d, sync flush per chunk, "
+                                    "%d indexes + footer parsed by xfg_index_parse, records cut by xfg_shard_plan over %d GPU(s)"
+                                    % (args.workload, shard["stream"]["raw_bytes"] / 2**30, n_chunks, chunk_size >> 10, "/".join(kinds), level,
+                                       shard["stream"]["indexes"], world),
+                        "stream_records": shard["stream"]["records"], "stream_bytes": shard["stream"]["bytes"],
+                        "records_per_rank": shard["stream"]["rank_records"],
+                        "raw_bytes_total": int(sum_raw), "comp_bytes_total": int(sum_comp),
+                        "ratio": round(sum_raw / sum_comp, 3), "verified_bit_exact": verified}
+                       if is_stream else
+                       {"workload": "%s: %d x %d KiB chunks per GPU (%s), zlib level %d, sync flush per chunk; "
+                                    "index-range sharded over %d GPU(s)" % (args.workload, n_chunks, chunk_size >> 10,
+                                                                           "/".join(kinds), level, world),
+                        "raw_bytes_per_gpu": raw_len, "comp_bytes_per_gpu": comp_len,
+                        "ratio": round(raw_len / comp_len, 3), "verified_bit_exact": verified}),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload),
                          "kernel": "inflate_chunks_kernel", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": algo_bytes if world == 1 else int(algo_bytes / world),
+                         "per": "GPU (achieved and peak are per GPU; launches of all ranks run side by side)"},
         }
         if not args.no_cpu and world == 1:                  # the CPU leg runs at N=1 only
             import oracle
             oracle.build()
-            threads = min(16, os.cpu_count() or 1)
+            # host threads: the CPU share this process has (the GPU box grants 16 CPUs per GPU and exports it as
+            # OMP_NUM_THREADS, while os.cpu_count() shows the whole machine); all of it is used and stated
+            visible = os.cpu_count() or 1
+            try:
+                share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+            except ValueError:
+                share = 0
+            threads = max(1, min(visible, share)) if share > 0 else min(visible, len(os.sched_getaffinity(0)))
             # about 20 core-seconds of CPU work: the whole shard, several times over; the mean rate is reported
             reps, total_dt, bad = 0, 0.0, 0
             while reps < 3 or (total_dt * threads < 20.0 and reps < 64):
@@ -288,7 +435,9 @@ def main():
                 bad += b
                 reps += 1
             out["cpu_baseline"] = {"value": round(raw_len * reps / total_dt / 1e9, 3), "unit": "GB/s", "cores": threads,
+                                   "host_cpus_visible": visible,
                                    "kind": "port",
+                                   "go": go_baseline_note(),
                                    "sample": "this rank's whole shard %d times (%d chunks, %.2f GiB raw each), "
                                              "oracle/inflate_oracle.c over %d host threads, %.1f s wall; %d bad chunks"
                                              % (reps, n, raw_len / 2**30, threads, total_dt, bad)}

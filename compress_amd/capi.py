@@ -13,7 +13,7 @@ MAX_CHUNK_COMP, MAX_CHUNK_RAW = (1 << 28) - 64, (1 << 31) - 64      # XFG_MAX_CH
 ST_OK, ST_CORRUPTED, ST_UNEXPECTED_EOF, ST_SIZE_MISMATCH, ST_NO_SYNC, ST_INTERNAL, ST_OUT_FULL = range(7)
 ST_NAMES = ["ok", "corrupted", "unexpected_eof", "size_mismatch", "no_sync", "internal", "out_full"]
 # chunk flags
-CHUNK_END_BLOCK, CHUNK_SYNC, CHUNK_VERIFY, CHUNK_FOOTER, CHUNK_RFC_REP16 = 1, 2, 4, 8, 16
+CHUNK_END_BLOCK, CHUNK_SYNC, CHUNK_VERIFY, CHUNK_FOOTER, CHUNK_RFC_REP16, CHUNK_HOST_META = 1, 2, 4, 8, 16, 32
 CHUNK_XFLATE_DEFLATE = CHUNK_END_BLOCK | CHUNK_SYNC | CHUNK_VERIFY | CHUNK_RFC_REP16
 CHUNK_XFLATE_INDEX = CHUNK_END_BLOCK | CHUNK_VERIFY | CHUNK_RFC_REP16
 CHUNK_XFLATE_FOOTER = CHUNK_END_BLOCK | CHUNK_VERIFY | CHUNK_FOOTER | CHUNK_RFC_REP16

@@ -542,8 +542,10 @@ int64_t xfg_reader::seek(int64_t off, int whence, int *e) {
 static uint32_t flags_for(int typ) {
     switch (typ) {
     case XFG_REC_DEFLATE: return XFG_CHUNK_XFLATE_DEFLATE;
-    case XFG_REC_INDEX: return XFG_CHUNK_XFLATE_INDEX;
-    default: return XFG_CHUNK_XFLATE_FOOTER;
+    // index and footer records were decoded block by block when the index was parsed (decode_index, decode_footer:
+    // every meta block valid, the record consumed to its last byte): the device does not inflate them a second time
+    case XFG_REC_INDEX: return XFG_CHUNK_XFLATE_INDEX | XFG_CHUNK_HOST_META;
+    default: return XFG_CHUNK_XFLATE_FOOTER | XFG_CHUNK_HOST_META;
     }
 }
 
@@ -593,7 +595,7 @@ int xfg_reader::ensure_decoded() {
         ch.raw_off = (uint64_t)ro;
         ch.raw_size = (uint64_t)rs;
         ch.flags = flags_for(c.type);
-        if (have != cs) ch.flags &= ~XFG_CHUNK_VERIFY;          // sizes are re-checked below against cs
+        if (have != cs) ch.flags &= ~(XFG_CHUNK_VERIFY | XFG_CHUNK_HOST_META);   // sizes are re-checked below against cs; a short record is inflated for real
         co += cs; ro += rs;
     }
     int rc = xfg_decode(ctx, win_comp.data(), win_comp.size(), win_chunks.data(), n,

@@ -1732,6 +1732,21 @@ __device__ void inflate_chunk(const u8 *__restrict__ comp, u64 comp_len, const x
         return;
     }
 
+    if (flags & XFG_CHUNK_HOST_META) {
+        // An index or footer record that the host decoded when it parsed the index: nothing to inflate
+        // (include/xflate_amd.h).  What inflating it yields: no output, every byte consumed (and the appended endBlock).
+        if (lane == 0) {
+            xfg_result out;
+            const i64 consumed = (i64)c.comp_size + ((flags & XFG_CHUNK_FOOTER) ? 0 : ((flags & XFG_CHUNK_END_BLOCK) ? 5 : 0));
+            out.status = ((flags & XFG_CHUNK_VERIFY) && c.raw_size != 0) ? XFG_ST_SIZE_MISMATCH : XFG_ST_OK;
+            out.reserved = 0;
+            out.in_consumed = consumed;
+            out.out_produced = 0;
+            res[ci] = out;
+        }
+        return;
+    }
+
     Reader r;
     r.comp = comp;
     r.base_al = c.comp_off & ~(u64)511;

@@ -125,6 +125,38 @@ def assemble_stream(comp_chunks, raw_sizes, index_size=xflate.DefaultIndexSize):
     return bytes(out)
 
 
+class _SparseOut(object):
+    """A writer that keeps what is written with its offset and can skip ahead: the index and footer of a
+    stream whose chunk bytes are never materialised."""
+    def __init__(self):
+        self.pos = 0
+        self.blobs = []          # (offset, bytes)
+
+    def write(self, b):
+        self.blobs.append((self.pos, bytes(b)))
+        self.pos += len(b)
+
+    def skip(self, n):
+        self.pos += n
+
+
+def assemble_sparse(comp_sizes, raw_sizes, index_size=xflate.DefaultIndexSize):
+    """The layout of the XFLATE stream assemble_stream() would build from chunks of these sizes, without the
+    chunks: -> (stream length, [(offset, bytes)...] for every index and the footer, in stream order).
+    Chunk i's bytes belong at the offsets the records say; the caller places (or tiles) them."""
+    out = _SparseOut()
+    w = xflate.Writer(out, xflate.WriterConfig(IndexSize=index_size))
+    for c, r in zip(comp_sizes, raw_sizes):
+        out.skip(c)
+        w.OutputOffset += c
+        lc, lr = w.idx.last()
+        w.idx.Records.append((lc + c, lr + r))
+        if len(w.idx.Records) == w.nidx:
+            w.Flush(xflate.FlushIndex)
+    w.Close()
+    return out.pos, out.blobs
+
+
 def build_mix_stream(n_chunks, chunk_size, kinds=("huffman", "repeats", "digits"), level=6,
                      strategy=zlib.Z_DEFAULT_STRATEGY, seed=1, n_distinct=None, threads=8,
                      index_size=xflate.DefaultIndexSize):

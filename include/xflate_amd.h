@@ -63,6 +63,14 @@ extern "C" {
 #define XFG_CHUNK_RFC_REP16  0x10u  /* code-length symbol 16 repeats the previous array entry (RFC 1951 / Go
                                        stdlib, the inflater xflate.Reader calls: xflate/flate.go:43); unset =
                                        the in-repo flate package's rule (flate/prefix.go:127-142)            */
+#define XFG_CHUNK_HOST_META  0x20u  /* an index or footer record whose meta blocks the HOST has already decoded, every one
+                                       valid and the record consumed to its last byte (decodeIndex / decodeFooter,
+                                       xflate/reader.go:354-483; what decodes as meta blocks inflates to nothing,
+                                       meta/meta_test.go:28-51).  The device does not inflate it a second time: it reports
+                                       status OK, out_produced 0 and the in_consumed that inflating would give (comp_size,
+                                       +5 with END_BLOCK unless FOOTER).  xfg_index_parse and the Reader set it; without it
+                                       the record is inflated like any chunk (one dynamic-block header per 12-64 bytes:
+                                       a 40 KB index record costs one wave about 80 ms). */
 /* what xflate.Reader implies for each record type */
 #define XFG_CHUNK_XFLATE_DEFLATE (XFG_CHUNK_END_BLOCK | XFG_CHUNK_SYNC | XFG_CHUNK_VERIFY | XFG_CHUNK_RFC_REP16)
 #define XFG_CHUNK_XFLATE_INDEX   (XFG_CHUNK_END_BLOCK | XFG_CHUNK_VERIFY | XFG_CHUNK_RFC_REP16)

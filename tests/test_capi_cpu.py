@@ -50,8 +50,9 @@ def test_index_parse_matches_oracle(i):
     assert err == capi.ERR_NONE, v["desc"]
     assert len(chunks) == len(xr.idx.records)
     pc = pr = 0
-    flags = {xo.DEFLATE_TYPE: capi.CHUNK_XFLATE_DEFLATE, xo.INDEX_TYPE: capi.CHUNK_XFLATE_INDEX,
-             xo.FOOTER_TYPE: capi.CHUNK_XFLATE_FOOTER}
+    # index and footer records carry HOST_META: the host decoded their meta blocks while parsing
+    flags = {xo.DEFLATE_TYPE: capi.CHUNK_XFLATE_DEFLATE, xo.INDEX_TYPE: capi.CHUNK_XFLATE_INDEX | capi.CHUNK_HOST_META,
+             xo.FOOTER_TYPE: capi.CHUNK_XFLATE_FOOTER | capi.CHUNK_HOST_META}
     for ch, (c, r, t) in zip(chunks, xr.idx.records):
         assert (ch.comp_off, ch.comp_size, ch.raw_off, ch.raw_size, ch.flags) == (pc, c - pc, pr, r - pr, flags[t])
         pc, pr = c, r

@@ -124,3 +124,27 @@ def test_current_device_is_restored(ctx):
     ctx.sync()
     assert hip.hipGetDevice(ctypes.byref(dev)) == 0 and dev.value == d0
     assert torch.cuda.current_device() == before
+
+
+def test_host_meta_shortcut_equals_inflating(ctx):
+    """XFG_CHUNK_HOST_META (index / footer records the host decoded while parsing the index) must report exactly what
+    inflating those records on the device reports: every valid stream of the reference's xflate vectors and a
+    synthetic stream with several indexes, decoded with the flag and with the flag stripped."""
+    from conftest import load_golden
+    from compress_amd import capi, synth
+    streams = [bytes.fromhex(v["input"]) for v in load_golden("xflate_reader.json")["vectors"] if not v["errf"]]
+    streams.append(synth.build_mix_stream(23, 5000, index_size=4)[0])
+    seen = 0
+    for stream in streams:
+        err, chunks = capi.index_parse(stream)
+        assert err == capi.ERR_NONE
+        raw_len = sum(c.raw_size for c in chunks)
+        with_flag = [(c.comp_off, c.comp_size, c.raw_off, c.raw_size, c.flags) for c in chunks]
+        without = [(c.comp_off, c.comp_size, c.raw_off, c.raw_size, c.flags & ~capi.CHUNK_HOST_META) for c in chunks]
+        seen += sum(1 for c in chunks if c.flags & capi.CHUNK_HOST_META)
+        raw_a, res_a = ctx.decode(stream, with_flag, raw_len)
+        raw_b, res_b = ctx.decode(stream, without, raw_len)
+        assert [(r.status, r.in_consumed, r.out_produced) for r in res_a] == [(r.status, r.in_consumed, r.out_produced) for r in res_b]
+        assert all(r.status == capi.ST_OK for r in res_a)
+        assert raw_a.raw[:raw_len] == raw_b.raw[:raw_len]
+    assert seen >= len(streams)                                  # every stream has a footer record at least
