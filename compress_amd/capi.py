@@ -49,7 +49,7 @@ SYMBOLS = [
     "xfg_reader_new", "xfg_reader_reset", "xfg_reader_read", "xfg_reader_seek", "xfg_reader_close",
     "xfg_reader_free", "xfg_reader_num_records", "xfg_reader_get_records", "xfg_reader_bytes_read",
     "xfg_reader_set_window", "xfg_index_parse", "xfg_shard_plan", "xfg_flate_decode",
-    "xfg_crc32_device", "xfg_crc32_combine",
+    "xfg_crc32_device", "xfg_crc32_combine", "xfg_decode_device_noalloc",
     "xfg_deflate_bound", "xfg_deflate", "xfg_deflate_device",
 ]
 
@@ -75,6 +75,7 @@ def lib():
     L.xfg_last_error.restype = ctypes.c_char_p
     L.xfg_decode.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
     L.xfg_decode_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    L.xfg_decode_device_noalloc.argtypes = [ctypes.c_int, vp, sz, vp, sz, vp, sz, vp, vp]
     L.xfg_sync.argtypes = [vp]
     L.xfg_reader_new.argtypes = [vp, READ_FN, SEEK_FN, vp, ctypes.POINTER(vp)]
     L.xfg_reader_reset.argtypes = [vp, READ_FN, SEEK_FN, vp]

@@ -51,7 +51,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 #include "../../include/xflate_amd.h"
+#include "xfg_internal.h"
 
 namespace xfg {
 
@@ -1975,6 +1977,81 @@ extern "C" size_t xfg_scratch_bytes(int num_cu)
 {
     (void)num_cu;
     return 64 * xfg::DRAW_SLICES;                               // the chunk counters; the token lists live in LDS, nothing is staged in HBM
+}
+
+// ---------------------------------------------------------------------------
+// xfg_decode_device_noalloc (include/xflate_amd.h): the same launch for callers that cannot allocate.
+// The only scratch buffer of the decode path is the chunk counters of the persistent grid (64 bytes per table
+// slice, 2 KB); here they live in a __device__ array of this code object instead of the context's hipMalloc'd
+// block.  Every GPU the library runs on holds its own copy of the array at its own address: the address is looked
+// up once per device, with that device current, and only that pointer -- never the array's name, which in host
+// code is a stand-in and no device address -- is handed to hipMemsetAsync and to the kernel.
+// ---------------------------------------------------------------------------
+namespace xfg {
+static __device__ __align__(256) unsigned char scratch[64 * DRAW_SLICES];   // (no attribute "used": with it clang keeps the symbol local and the runtime cannot find it)
+}
+
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+struct NoAllocDevice {
+    void *ptr;          // device address of xfg::scratch on this device
+    int num_cu;
+};
+NoAllocDevice g_noalloc[NOALLOC_MAX_DEVICES];
+bool g_noalloc_done[NOALLOC_MAX_DEVICES];                       // guarded by g_noalloc_mutex
+hipError_t g_noalloc_err[NOALLOC_MAX_DEVICES];
+std::mutex g_noalloc_mutex;
+
+// once per device, with that device current
+void noalloc_setup(int device)
+{
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(xfg::scratch));
+    int ncu = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    if (e == hipSuccess && (p == nullptr || ncu <= 0)) e = hipErrorInvalidValue;
+    g_noalloc[device].ptr = p;
+    g_noalloc[device].num_cu = ncu;
+    g_noalloc_err[device] = e;
+}
+}
+
+extern "C" int xfg_decode_device_noalloc(int device, const void *d_comp, size_t comp_len,
+                                         const void *d_chunks, size_t n,
+                                         void *d_raw, size_t raw_len, void *d_res, void *hip_stream)
+{
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) { xfg_set_last_error("xfg_decode_device_noalloc: device index out of range"); return XFG_E_ARG; }
+    if (n > (1ull << 30)) {
+        xfg_set_last_error("xfg_decode_device_noalloc: more than 2^30 chunks in one call (the chunk counters count to 3 n in 32 bits)");
+        return XFG_E_LIMIT;
+    }
+    if (n != 0 && (!d_comp || !d_chunks || !d_res || (!d_raw && raw_len) || ((uintptr_t)d_comp & 15) != 0)) {
+        xfg_set_last_error("xfg_decode_device_noalloc: null or misaligned device pointer");
+        return XFG_E_ARG;
+    }
+    // the caller's current device is put back on every way out
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) {
+        const hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) { xfg_set_last_error(hipGetErrorString(e)); return XFG_E_NODEVICE; }
+    }
+    int rc = XFG_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+        if (!g_noalloc_done[device]) { noalloc_setup(device); g_noalloc_done[device] = true; }
+    }
+    if (g_noalloc_err[device] != hipSuccess) {
+        xfg_set_last_error(hipGetErrorString(g_noalloc_err[device]));
+        rc = XFG_E_HIP;
+    } else if (n != 0) {
+        void *ptr = g_noalloc[device].ptr;                      // the device address, never the symbol
+        const hipError_t e = xfg_launch_inflate(d_comp, comp_len, d_chunks, (uint32_t)n, d_raw, raw_len, d_res, ptr,
+                                                g_noalloc[device].num_cu, (hipStream_t)hip_stream);
+        if (e != hipSuccess) { xfg_set_last_error(hipGetErrorString(e)); rc = XFG_E_HIP; }
+    }
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    return rc;
 }
 
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, const void *d_chunks, uint32_t n,

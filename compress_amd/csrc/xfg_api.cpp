@@ -49,6 +49,7 @@ struct DeviceGuard {
     } while (0)
 
 extern "C" const char *xfg_last_error(void) { return g_last_error.c_str(); }
+extern "C" void xfg_set_last_error(const char *text) { g_last_error = text ? text : ""; }
 
 extern "C" const char *xfg_strerror(int code) {
     switch (code) {

@@ -9,6 +9,8 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, co
                                          void *d_raw, size_t raw_len, void *d_res, void *d_scratch,
                                          int num_cu, hipStream_t stream);
 extern "C" size_t xfg_scratch_bytes(int num_cu);
+// text for xfg_last_error() on the calling thread (xfg_api.cpp)
+extern "C" void xfg_set_last_error(const char *text);
 extern "C" hipError_t xfg_launch_crc32(const void *d_raw, size_t raw_len, const void *d_chunks, const void *d_res, uint32_t n,
                                        void *d_crc, int num_cu, hipStream_t stream);
 extern "C" hipError_t xfg_launch_deflate(const void *d_raw, size_t raw_len, const void *d_chunks, uint32_t n,

@@ -145,6 +145,22 @@ int xfg_decode_device(xfg_ctx *ctx, const void *d_comp, size_t comp_len,
                       const void *d_chunks, size_t n,
                       void *d_raw, size_t raw_len, void *d_res, void *hip_stream);
 /*
+ * xfg_decode_device for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference (which allocates freely, being Go); it
+ * exists for those callers only.  It takes no context: the one scratch buffer of the decode path, the chunk
+ * counters of the persistent grid (2048 bytes), is a __device__ array of the library's code object that every
+ * GPU the library runs on holds until the process ends.  The call makes no hipMalloc / hipFree and calls no
+ * allocating routine; apart from the first call on a device (which looks up the array's device address and the
+ * CU count: call once with n = 0 outside any capture to do just that) it enqueues one 2 KB memset and the kernel
+ * on hip_stream (NULL = the null stream) and returns without synchronising.  Arguments, per-chunk results and the
+ * trust rules are xfg_decode_device's.  Limit: n <= 2^30 chunks per call, more is refused with XFG_E_LIMIT.
+ * All calls on one GPU share that GPU's counters: two calls that may run at the same time on one GPU race --
+ * keep them on one stream, or order them.  The calling thread's current device is left as it was.
+ */
+int xfg_decode_device_noalloc(int device, const void *d_comp, size_t comp_len,
+                              const void *d_chunks, size_t n,
+                              void *d_raw, size_t raw_len, void *d_res, void *hip_stream);
+/*
  * CRC-32 (IEEE 802.3: Go's hash/crc32.IEEE, the checksum of gzip trailers and of the XFLATE
  * index, xflate/reader.go:386) of every chunk's decoded bytes, computed where they are: the
  * reference's gzip embedding hashes on the CPU while writing (xflate/example_test.go:171-182),
