@@ -40,11 +40,12 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 
 def measured_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 counter passes (profiles/r2/traffic.json), or None.
-    FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes), WRITE_SIZE is exact; both in KB."""
+    """Fabric-side bytes per launch from the committed rocprofv3 counter passes (profiles/r2/traffic.json), or None.
+    FETCH_SIZE counts the narrow match-source loads 1 : 1 (64 bytes per scattered load) and the wide coalesced reads of the
+    compressed bytes at half (calibrated: profiles/r2/calibration_narrow_loads.txt), WRITE_SIZE is exact; both in KB."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r2", "traffic.json")))[workload]
-        return int((2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024)
+        return int((t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024 + t["comp_bytes"] // 2)
     except (OSError, KeyError, ValueError):
         return None
 
