@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from compress_amd import capi  # noqa: E402
 
-bench.WORKLOADS["host"] = (4096, 65536, ("huffman", "repeats", "digits"), 6, 768)
+NCHUNKS = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+bench.WORKLOADS["host"] = (NCHUNKS, 65536, ("huffman", "repeats", "digits"), 6, 768)
 shard = bench.build_shard("host", 0)
 ctx = capi.Context(0)
 n = shard["n"]
@@ -19,7 +20,7 @@ raw = ctypes.create_string_buffer(shard["raw_len"])
 res = (capi.Result * n)()
 comp = shard["comp"]
 L = capi.lib()
-for it in range(4):
+for it in range(8):
     t0 = time.perf_counter()
     rc = L.xfg_decode(ctx._h, comp, len(comp), shard["descs"], n, raw, shard["raw_len"], res)
     dt = time.perf_counter() - t0
