@@ -332,7 +332,25 @@ struct xfg_reader {
     int64_t win_first;
     std::vector<xfg_result> win_res;
     std::vector<xfg_chunk> win_chunks;
-    Bytes win_raw, win_comp;
+    // the window's compressed and decoded bytes: grown, never zero-filled (a std::vector's resize costs as much as the
+    // decode), kept from window to window
+    struct Span {
+        uint8_t *p; size_t cap, len;
+        Span() : p(nullptr), cap(0), len(0) {}
+        ~Span() { free(p); }
+        Span(const Span &) = delete;
+        Span &operator=(const Span &) = delete;
+        bool fit(size_t n) {                                    // contents are not kept
+            len = 0;
+            if (n <= cap) return true;
+            free(p);
+            cap = n + n / 2 + 4096;
+            p = (uint8_t *)malloc(cap);
+            if (!p) { cap = 0; return false; }
+            return true;
+        }
+    };
+    Span win_raw, win_comp;
     std::vector<uint8_t> win_sync_ok;
     int64_t max_window_raw;
     int64_t ahead;         // chunks to decode in the next launch (doubles while sequential)
@@ -351,6 +369,21 @@ struct xfg_reader {
             dst.insert(dst.end(), tmp, tmp + k);
             got += k; bytes_read += k;
         }
+        return got;
+    }
+
+    // the same into a Span's memory, in large pieces (one call of the callback per piece)
+    int64_t rs_read_into(Span &dst, int64_t n) {
+        if (!dst.fit((size_t)n + 16)) return -1;
+        int64_t got = 0;
+        while (got < n) {
+            const int64_t want = std::min<int64_t>(n - got, 16 << 20);
+            const int64_t k = rd_fn(user, dst.p + got, want);
+            if (k < 0) return -1;
+            if (k == 0) break;
+            got += k; bytes_read += k;
+        }
+        dst.len = (size_t)got;
         return got;
     }
 
@@ -571,16 +604,15 @@ int xfg_reader::ensure_decoded() {
     const size_t n = (size_t)(last - cur_rec + 1);
     if (ahead < (1 << 20)) ahead *= 2;
 
-    win_comp.clear();
     if (rs_seek(p0.comp_offset, 0) < 0) return XFG_ERR_IO;
-    const int64_t got = rs_read_n(win_comp, comp_total);
+    const int64_t got = rs_read_into(win_comp, comp_total);
     if (got < 0) return XFG_ERR_IO;
     // A short read means the index promised more bytes than the stream has; the chunk
     // reader of the reference then ends the chunk early.  Shrink the affected chunks.
     win_chunks.resize(n);
     win_res.resize(n);
     win_sync_ok.resize(n);
-    win_raw.resize((size_t)raw_total + 16);
+    if (!win_raw.fit((size_t)raw_total + 16)) return XFG_ERR_INTERNAL;
     int64_t co = 0, ro = 0;
     for (size_t i = 0; i < n; i++) {
         xfg_record p, c;
@@ -598,8 +630,8 @@ int xfg_reader::ensure_decoded() {
         if (have != cs) ch.flags &= ~(XFG_CHUNK_VERIFY | XFG_CHUNK_HOST_META);   // sizes are re-checked below against cs; a short record is inflated for real
         co += cs; ro += rs;
     }
-    int rc = xfg_decode(ctx, win_comp.data(), win_comp.size(), win_chunks.data(), n,
-                        win_raw.data(), (size_t)raw_total, win_res.data());
+    int rc = xfg_decode(ctx, win_comp.p, win_comp.len, win_chunks.data(), n,
+                        win_raw.p, (size_t)raw_total, win_res.data());
     if (rc != XFG_OK) { win_res.clear(); return XFG_ERR_DEVICE; }
     // restore the promised csize for the size check of truncated chunks
     co = 0;
@@ -630,7 +662,7 @@ int64_t xfg_reader::zr_read(uint8_t *buf, int64_t n, int *e) {
     const int64_t have = res.out_produced - cur_rd;
     if (have > 0) {
         const int64_t k = std::min(have, n);
-        if (buf) memcpy(buf, win_raw.data() + win_chunks[wi].raw_off + cur_rd, (size_t)k);
+        if (buf) memcpy(buf, win_raw.p + win_chunks[wi].raw_off + cur_rd, (size_t)k);
         cur_rd += k;
         return k;
     }

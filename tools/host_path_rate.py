@@ -27,3 +27,29 @@ for it in range(8):
     assert rc == 0 and all(res[i].status == 0 for i in range(0, n, 97))
     print("xfg_decode host path: %.1f MiB raw in %.2f ms = %.2f GB/s decompressed" % (shard["raw_len"] / 2**20, dt * 1e3, shard["raw_len"] / dt / 1e9))
 ctx.close()
+
+# ---- the same chunks as one XFLATE stream, read sequentially through xfg_reader (xflate.Reader.Read): the source
+# callback copies from a resident buffer, reads are 64 MiB
+import io
+from compress_amd import synth, xflate  # noqa: E402
+
+stream, _ = synth.build_mix_stream(NCHUNKS, 65536, n_distinct=768)
+total = NCHUNKS * 65536
+rd, e = xflate.NewReader(io.BytesIO(stream))
+assert e is None, e
+buf = ctypes.create_string_buffer(64 << 20)
+for it in range(5):
+    if it:
+        rd.Reset(io.BytesIO(stream))                # the Reader keeps its window buffers
+    err = ctypes.c_int()
+    got = 0
+    t0 = time.perf_counter()
+    while True:
+        k = L.xfg_reader_read(rd._h, buf, len(buf), ctypes.byref(err))
+        if k <= 0:
+            break
+        got += k
+    dt = time.perf_counter() - t0
+    assert got == total and err.value == capi.ERR_EOF, (got, err.value)
+    print("xfg_reader sequential Read: %.1f MiB in %.2f ms = %.2f GB/s (%d bytes read from the source)" % (got / 2**20, dt * 1e3, got / dt / 1e9, rd.bytes_read()))
+rd.Close()
