@@ -181,6 +181,30 @@ class Context:
             out.append(comp.raw[arr[i].comp_off:arr[i].comp_off + res[i].out_produced])
         return out
 
+    def deflate_chunks(self, chunks):
+        """xfg_deflate over chunks of any sizes (a list of bytes-like) in one launch -> list of compressed chunks."""
+        n = len(chunks)
+        if n == 0:
+            return []
+        raw = b"".join(bytes(c) for c in chunks)
+        arr = (Chunk * n)()
+        co = ro = 0
+        for i, c in enumerate(chunks):
+            b = lib().xfg_deflate_bound(len(c))
+            arr[i] = Chunk(co, b, ro, len(c), 0, 0)
+            co += b
+            ro += len(c)
+        res = (Result * n)()
+        comp = ctypes.create_string_buffer(max(co, 1))
+        check(lib().xfg_deflate(self._h, raw, len(raw), arr, n, comp, co, res), "xfg_deflate")
+        mv = memoryview(comp).cast("B")
+        out = []
+        for i in range(n):
+            if res[i].status != ST_OK:
+                raise TransportError("xfg_deflate: chunk %d status %s" % (i, ST_NAMES[res[i].status]))
+            out.append(bytes(mv[arr[i].comp_off:arr[i].comp_off + res[i].out_produced]))
+        return out
+
     def deflate_device(self, d_raw, raw_len, d_chunks, n, d_comp, comp_len, d_res, stream=None):
         """xfg_deflate_device (async); pointers are ints."""
         check(lib().xfg_deflate_device(self._h, d_raw, raw_len, d_chunks, n, d_comp, comp_len, d_res,

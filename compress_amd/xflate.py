@@ -353,6 +353,105 @@ class Writer(object):
         self._emit(bytes(mw.out))
 
 
-def NewWriter(wr, conf=None):
-    """xflate.NewWriter (writer.go:78-104)."""
+class GpuWriter(Writer):
+    """xflate.Writer whose chunks are compressed on the GPU (xfg_deflate, csrc/deflate_kernel.hip) instead of by
+    zlib: the chunker, the index and the footer are the Writer's (writer.go:138-298).  Closed chunks wait in a
+    queue and are compressed `batch_chunks` at a time in one launch (one wave per chunk: a launch per chunk would
+    leave the GPU empty), so OutputOffset and the records lag behind InputOffset until the queue is drained --
+    by a sync flush, an index, Close, or a full queue.  A sync flush inside a chunk compresses what the chunk holds
+    so far as a segment of its own (every segment ends in 00 00 ff ff and starts without history: the
+    concatenation is what a DEFLATE stream with sync flushes is).  Level is ignored: the device compressor has one."""
+
+    def __init__(self, wr, conf=None, ctx=None, batch_chunks=1024):
+        self._ctx = ctx
+        self._batch = max(1, int(batch_chunks))
+        Writer.__init__(self, wr, conf)
+
+    def _zreset(self):
+        self._pend = bytearray()           # bytes of the current chunk not yet compressed
+        self._zin = self._zout = 0
+
+    def Reset(self, wr):
+        self._queue = []                   # closed chunks: (raw bytes, compressed bytes already emitted for it, raw size)
+        Writer.Reset(self, wr)
+
+    def _drain(self):
+        if not self._queue:
+            return
+        ctx = self._ctx or default_context()
+        todo = [q[0] for q in self._queue if len(q[0])]
+        comp = iter(ctx.deflate_chunks(todo))
+        for raw, zout, zin in self._queue:
+            c = next(comp) if len(raw) else b"\x00\x00\x00\xff\xff"    # the empty stored block of a sync flush
+            self._emit(c)
+            lc, lr = self.idx.last()
+            self.idx.Records.append((lc + zout + len(c), lr + zin))
+        self._queue = []
+
+    def Write(self, buf):
+        if self.err is not None:
+            raise self.err
+        buf = memoryview(bytes(buf))
+        cnt = 0
+        while len(buf) > 0:
+            remain = self.nchk - self._zin
+            if remain <= 0:
+                self.Flush(FlushFull)
+                continue
+            remain = min(remain, len(buf))
+            self._pend += buf[:remain]
+            self._zin += remain
+            buf = buf[remain:]
+            cnt += remain
+        self.InputOffset += cnt
+        return cnt
+
+    def Flush(self, mode):
+        if self.err is not None:
+            raise self.err
+        if mode == FlushSync:
+            self._drain()                  # bytes leave in stream order
+            if self._pend:
+                ctx = self._ctx or default_context()
+                out = ctx.deflate_chunks([bytes(self._pend)])[0]
+                self._pend = bytearray()
+            else:
+                out = b"\x00\x00\x00\xff\xff"
+            self._zout += len(out)
+            self._emit(out)
+        elif mode == FlushFull:
+            self._queue.append((bytes(self._pend), self._zout, self._zin))
+            self._zreset()
+            if len(self.idx.Records) + len(self._queue) == self.nidx:
+                self.Flush(FlushIndex)
+            elif len(self._queue) >= self._batch:
+                self._drain()
+        elif mode == FlushIndex:
+            if self._zin + self._zout > 0:
+                self.Flush(FlushFull)      # (may itself write a full index; an empty one follows, as in the reference)
+            self._drain()
+            self._encode_index(self.idx)
+            back = self.idx.IndexSize
+            self.idx = _Index()
+            self.idx.BackSize = back
+        else:
+            raise _errorf(errors.Invalid, "invalid flush mode: %d" % mode)
+
+    def Close(self):
+        if self.err is not None:
+            if errors.IsClosed(self.err):
+                return
+            raise self.err
+        if self._zout + self._zin > 0 or len(self.idx.Records) > 0 or self._queue:
+            self.Flush(FlushIndex)
+        self._encode_footer(self.idx.BackSize)
+        self.err = _errClosed
+
+
+def NewWriter(wr, conf=None, compressor="zlib", ctx=None):
+    """xflate.NewWriter (writer.go:78-104).  compressor="gpu": chunks are compressed by xfg_deflate (GpuWriter)."""
+    if compressor == "gpu":
+        return GpuWriter(wr, conf, ctx=ctx)
+    if compressor != "zlib":
+        raise _errorf(errors.Invalid, "unknown compressor: %r" % (compressor,))
     return Writer(wr, conf)
