@@ -46,7 +46,7 @@ SEEK_FN = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctyp
 SYMBOLS = [
     "xfg_device_count", "xfg_create", "xfg_destroy", "xfg_strerror", "xfg_last_error",
     "xfg_decode", "xfg_decode_device", "xfg_sync",
-    "xfg_reader_new", "xfg_reader_reset", "xfg_reader_read", "xfg_reader_seek", "xfg_reader_close",
+    "xfg_reader_new", "xfg_reader_new_mem", "xfg_reader_reset_mem", "xfg_reader_reset", "xfg_reader_read", "xfg_reader_seek", "xfg_reader_close",
     "xfg_reader_free", "xfg_reader_num_records", "xfg_reader_get_records", "xfg_reader_bytes_read",
     "xfg_reader_set_window", "xfg_index_parse", "xfg_shard_plan", "xfg_flate_decode",
     "xfg_crc32_device", "xfg_crc32_combine", "xfg_decode_device_noalloc",
@@ -78,6 +78,8 @@ def lib():
     L.xfg_decode_device_noalloc.argtypes = [ctypes.c_int, vp, sz, vp, sz, vp, sz, vp, vp]
     L.xfg_sync.argtypes = [vp]
     L.xfg_reader_new.argtypes = [vp, READ_FN, SEEK_FN, vp, ctypes.POINTER(vp)]
+    L.xfg_reader_new_mem.argtypes = [vp, vp, sz, ctypes.POINTER(vp)]
+    L.xfg_reader_reset_mem.argtypes = [vp, vp, sz]
     L.xfg_reader_reset.argtypes = [vp, READ_FN, SEEK_FN, vp]
     L.xfg_reader_read.argtypes = [vp, vp, i64, ctypes.POINTER(ctypes.c_int)]
     L.xfg_reader_read.restype = i64

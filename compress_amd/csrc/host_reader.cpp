@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <new>
 #include <vector>
+#include "xfg_internal.h"
 
 #include "../../include/xflate_amd.h"
 
@@ -310,6 +311,31 @@ const int64_t kMaxInt64 = 0x7fffffffffffffffLL;
 } // namespace
 
 // ---------------------------------------------------------------- reader ---
+// bytes.NewReader over memory the caller keeps alive: the io.ReadSeeker of xfg_reader_new_mem
+namespace {
+struct MemSource { const uint8_t *p; int64_t len, pos; };
+int64_t mem_read(void *user, uint8_t *buf, int64_t n) {
+    MemSource *m = (MemSource *)user;
+    const int64_t k = std::max<int64_t>(0, std::min<int64_t>(n, m->len - m->pos));
+    if (k > 0) memcpy(buf, m->p + m->pos, (size_t)k);
+    m->pos += k;
+    return k;
+}
+int64_t mem_seek(void *user, int64_t off, int whence) {                // bytes.Reader.Seek
+    MemSource *m = (MemSource *)user;
+    int64_t base;
+    switch (whence) {
+    case 0: base = 0; break;
+    case 1: base = m->pos; break;
+    case 2: base = m->len; break;
+    default: return -1;
+    }
+    if (off < -base) return -1;
+    m->pos = base + off;
+    return m->pos;
+}
+}
+
 struct xfg_reader {
     xfg_ctx *ctx;
     xfg_read_fn rd_fn; xfg_seek_fn sk_fn; void *user;
@@ -353,6 +379,11 @@ struct xfg_reader {
     Span win_raw, win_comp;
     std::vector<uint8_t> win_sync_ok;
     int64_t max_window_raw;
+    int64_t want_raw = 0;        // bytes the Read in progress asks for: the window covers them if it has to be decoded anyway
+    uint8_t *direct_dst = nullptr;   // set by a large Read: decode the window straight into the caller's buffer ...
+    int64_t direct_cap = 0;          // ... of this many bytes (whole chunks only)
+    bool win_direct = false;         // the window's bytes lie in the caller's buffer: valid during that Read only
+    void *owned_src = nullptr;   // the MemSource of xfg_reader_new_mem (freed with the reader; a Reset to callbacks leaves it unused)
     int64_t ahead;         // chunks to decode in the next launch (doubles while sequential)
 
     // ---- io.ReadSeeker plumbing
@@ -590,11 +621,12 @@ int xfg_reader::ensure_decoded() {
     int64_t raw_total = 0, comp_total = 0;
     xfg_record p0, c0;
     idx.get_records(cur_rec, &p0, &c0);
-    for (int64_t k = cur_rec; k < nrec && k < cur_rec + ahead; k++) {
+    for (int64_t k = cur_rec; k < nrec && (k < cur_rec + ahead || raw_total < want_raw); k++) {
         xfg_record p, c;
         idx.get_records(k, &p, &c);
         const int64_t cs = c.comp_offset - p.comp_offset, rs = c.raw_offset - p.raw_offset;
         if (k > cur_rec && (raw_total + rs > max_window_raw || comp_total + cs > max_window_raw)) break;
+        if (direct_dst && raw_total + rs > direct_cap) break;   // (the caller made sure that the first chunk fits)
         if ((uint64_t)cs > XFG_MAX_CHUNK_COMP || (uint64_t)rs > XFG_MAX_CHUNK_RAW) {
             if (k == cur_rec) return XFG_ERR_LIMIT;             // documented per-chunk limit of the kernels (the reference has none)
             break;
@@ -602,17 +634,30 @@ int xfg_reader::ensure_decoded() {
         raw_total += rs; comp_total += cs; last = k;
     }
     const size_t n = (size_t)(last - cur_rec + 1);
-    if (ahead < (1 << 20)) ahead *= 2;
+    if (ahead < (1 << 20)) ahead = std::max<int64_t>(ahead * 2, std::min<int64_t>(2 * (int64_t)n, 1 << 20));
 
-    if (rs_seek(p0.comp_offset, 0) < 0) return XFG_ERR_IO;
-    const int64_t got = rs_read_into(win_comp, comp_total);
-    if (got < 0) return XFG_ERR_IO;
+    const uint8_t *comp_ptr;
+    int64_t got;
+    if (rd_fn == mem_read) {
+        // a stream in memory is decoded from where it lies
+        MemSource *m = (MemSource *)user;
+        got = std::max<int64_t>(0, std::min<int64_t>(comp_total, m->len - p0.comp_offset));
+        comp_ptr = m->p + std::min<int64_t>(p0.comp_offset, m->len);
+        m->pos = std::min<int64_t>(p0.comp_offset, m->len) + got;
+        bytes_read += got;
+    } else {
+        if (rs_seek(p0.comp_offset, 0) < 0) return XFG_ERR_IO;
+        got = rs_read_into(win_comp, comp_total);
+        if (got < 0) return XFG_ERR_IO;
+        comp_ptr = win_comp.p;
+    }
     // A short read means the index promised more bytes than the stream has; the chunk
     // reader of the reference then ends the chunk early.  Shrink the affected chunks.
     win_chunks.resize(n);
     win_res.resize(n);
     win_sync_ok.resize(n);
-    if (!win_raw.fit((size_t)raw_total + 16)) return XFG_ERR_INTERNAL;
+    win_direct = direct_dst != nullptr;
+    if (!win_direct && !win_raw.fit((size_t)raw_total + 16)) return XFG_ERR_INTERNAL;
     int64_t co = 0, ro = 0;
     for (size_t i = 0; i < n; i++) {
         xfg_record p, c;
@@ -630,9 +675,9 @@ int xfg_reader::ensure_decoded() {
         if (have != cs) ch.flags &= ~(XFG_CHUNK_VERIFY | XFG_CHUNK_HOST_META);   // sizes are re-checked below against cs; a short record is inflated for real
         co += cs; ro += rs;
     }
-    int rc = xfg_decode(ctx, win_comp.p, win_comp.len, win_chunks.data(), n,
-                        win_raw.p, (size_t)raw_total, win_res.data());
-    if (rc != XFG_OK) { win_res.clear(); return XFG_ERR_DEVICE; }
+    int rc = xfg_decode(ctx, comp_ptr, (size_t)got, win_chunks.data(), n,
+                        win_direct ? direct_dst : win_raw.p, (size_t)raw_total, win_res.data());
+    if (rc != XFG_OK) { win_res.clear(); win_direct = false; return XFG_ERR_DEVICE; }
     // restore the promised csize for the size check of truncated chunks
     co = 0;
     for (size_t i = 0; i < n; i++) {
@@ -693,6 +738,49 @@ int64_t xfg_reader::read(uint8_t *buf, int64_t n, int *e) {
         discard = 0;
     }
     if (n <= 0) return 0;
+    // Many whole chunks in one call.  What one Read per chunk would do, done at once for a run of chunks of the decoded
+    // window that ended cleanly with every post-chunk check passed (status OK): their bytes lie side by side in the
+    // window and leave in one copy on the context's helper threads; the state then steps over them record by record
+    // exactly as the loop below does at each chunk's io.EOF.  Anything else -- one chunk, an error, a short request --
+    // takes the loop below.
+    if (n >= (1 << 20) && cur_rec >= 0 && ctx) {
+        // A request of 32 MiB and more that needs a new window anyway has it decoded straight into the caller's buffer
+        // (io.Reader: "it may use all of p as scratch space during the call"): no window copy, no copy out.  Such a
+        // window is gone when the call returns; what was not delivered from it is decoded again.
+        const bool in_win = cur_rec >= win_first && cur_rec < win_first + (int64_t)win_res.size();
+        if (!in_win && n >= (32 << 20) && cur_rd == 0 && chk_rsize <= n) { direct_dst = buf; direct_cap = n; }
+        want_raw = n;
+        const int rc = ensure_decoded();
+        want_raw = 0;
+        direct_dst = nullptr;
+        if (rc == XFG_ERR_NONE) {
+            const size_t wi = (size_t)(cur_rec - win_first);
+            size_t wj = wi;
+            int64_t bytes = 0;
+            while (wj < win_res.size()) {
+                const xfg_result &r = win_res[wj];
+                if (r.status != XFG_ST_OK || r.out_produced != (int64_t)win_chunks[wj].raw_size) break;
+                const int64_t have = r.out_produced - (wj == wi ? cur_rd : 0);
+                if (have < 0 || bytes + have > n) break;
+                bytes += have;
+                wj++;
+            }
+            if (bytes > 0 && (win_direct || wj - wi >= 2)) {
+                if (!win_direct) xfg_host_copy(ctx, buf, win_raw.p + win_chunks[wi].raw_off + cur_rd, (size_t)bytes);
+                for (size_t k = wi; k < wj && err == XFG_ERR_NONE; k++) {
+                    offset += win_res[k].out_produced - (k == wi ? cur_rd : 0);
+                    cur_in_off = win_res[k].in_consumed;
+                    int se;
+                    seek(offset, 0, &se);
+                    if (se != XFG_ERR_NONE) { err = se; break; }
+                    if (chk_typ == XFG_REC_UNKNOWN) err = XFG_ERR_EOF;
+                }
+                if (win_direct) { win_res.clear(); win_direct = false; }
+                return bytes;                                   // (an error, if any, surfaces on the next call)
+            }
+        }
+        if (win_direct) { win_res.clear(); win_direct = false; }   // nothing clean at its head: the loop below decodes into the window
+    }
     int64_t cnt = 0;
     while (cnt == 0 && err == XFG_ERR_NONE) {
         int ze;
@@ -737,6 +825,27 @@ extern "C" int xfg_reader_new(xfg_ctx *ctx, xfg_read_fn rd, xfg_seek_fn sk, void
     *out = r;
     return r->reset(rd, sk, user);
 }
+extern "C" int xfg_reader_new_mem(xfg_ctx *ctx, const uint8_t *stream, size_t len, xfg_reader **out) {
+    if (!out) return XFG_ERR_INVALID;
+    *out = nullptr;
+    if (!ctx || (!stream && len) || len > (size_t)INT64_MAX) return XFG_ERR_INVALID;
+    MemSource *m = new (std::nothrow) MemSource{stream, (int64_t)len, 0};
+    if (!m) return XFG_ERR_INTERNAL;
+    const int rc = xfg_reader_new(ctx, mem_read, mem_seek, m, out);
+    if (*out) (*out)->owned_src = m; else delete m;
+    return rc;
+}
+extern "C" int xfg_reader_reset_mem(xfg_reader *r, const uint8_t *stream, size_t len) {
+    if (!r || (!stream && len) || len > (size_t)INT64_MAX) return XFG_ERR_INVALID;
+    MemSource *m = (MemSource *)r->owned_src;
+    if (!m) {
+        m = new (std::nothrow) MemSource();
+        if (!m) return XFG_ERR_INTERNAL;
+        r->owned_src = m;
+    }
+    m->p = stream; m->len = (int64_t)len; m->pos = 0;
+    return r->reset(mem_read, mem_seek, m);
+}
 extern "C" int xfg_reader_reset(xfg_reader *r, xfg_read_fn rd, xfg_seek_fn sk, void *user) {
     if (!r || !rd || !sk) return XFG_ERR_INVALID;
     return r->reset(rd, sk, user);
@@ -756,7 +865,12 @@ extern "C" int64_t xfg_reader_seek(xfg_reader *r, int64_t offset, int whence, in
     return p;
 }
 extern "C" int xfg_reader_close(xfg_reader *r) { return r ? r->close() : XFG_ERR_INVALID; }
-extern "C" void xfg_reader_free(xfg_reader *r) { delete r; }
+extern "C" void xfg_reader_free(xfg_reader *r) {
+    if (!r) return;
+    void *src = r->owned_src;
+    delete r;
+    delete (MemSource *)src;
+}
 extern "C" int64_t xfg_reader_num_records(const xfg_reader *r) { return r ? (int64_t)r->idx.records.size() : 0; }
 extern "C" int xfg_reader_get_records(const xfg_reader *r, xfg_record *out, int64_t cap) {
     if (!r || (!out && cap > 0)) return XFG_ERR_INVALID;
@@ -772,27 +886,9 @@ extern "C" int xfg_reader_set_window(xfg_reader *r, int64_t max_raw_bytes) {
 }
 
 // Index-only use: parse an in-memory stream and emit the device chunk table.
-namespace {
-struct MemSrc { const uint8_t *p; int64_t n, pos; };
-int64_t mem_read(void *u, uint8_t *buf, int64_t n) {
-    MemSrc *m = (MemSrc *)u;
-    const int64_t k = std::max<int64_t>(0, std::min(n, m->n - m->pos));
-    if (k) memcpy(buf, m->p + m->pos, (size_t)k);
-    m->pos += k;
-    return k;
-}
-int64_t mem_seek(void *u, int64_t off, int whence) {
-    MemSrc *m = (MemSrc *)u;
-    int64_t p = whence == 0 ? off : (whence == 1 ? m->pos + off : m->n + off);
-    if (p < 0) return -1;
-    m->pos = p;
-    return p;
-}
-}
-
 extern "C" int xfg_index_parse(const uint8_t *stream, size_t len, xfg_chunk *chunks, size_t cap, size_t *n_out) {
     if ((!stream && len) || !n_out) return XFG_ERR_INVALID;
-    MemSrc src = { stream, (int64_t)len, 0 };
+    MemSource src = { stream, (int64_t)len, 0 };
     xfg_reader r;
     r.ctx = nullptr;
     r.max_window_raw = 256ll << 20;
@@ -882,7 +978,7 @@ extern "C" void xfg_test_index_get_records(const void *idx, int64_t i, xfg_recor
     ((const Index *)idx)->get_records(i, prev, curr);
 }
 extern "C" int xfg_test_decode_index(const uint8_t *enc, size_t len, void *idx, int64_t *back_size) {
-    MemSrc src = { enc, (int64_t)len, 0 };
+    MemSource src = { enc, (int64_t)len, 0 };
     xfg_reader r;
     r.ctx = nullptr;
     r.rd_fn = mem_read; r.sk_fn = mem_seek; r.user = &src;

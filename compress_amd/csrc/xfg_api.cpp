@@ -282,6 +282,13 @@ void parallel_copy(HostPool *pool, uint8_t *dst, const uint8_t *src, size_t len)
 }
 }
 
+// A large host-to-host copy on the context's helper threads (the Reader's copy into the caller's buffer).
+extern "C" void xfg_host_copy(xfg_ctx *c, void *dst, const void *src, size_t n) {
+    if (c && n >= (4u << 20) && !c->pool) c->pool = new (std::nothrow) HostPool(kCopyThreads + 1);
+    if (!c || !c->pool || n < (4u << 20)) { memcpy(dst, src, n); return; }
+    parallel_copy(c->pool, (uint8_t *)dst, (const uint8_t *)src, n);
+}
+
 static int decode_pipelined(xfg_ctx *c, const uint8_t *comp, size_t comp_len, const xfg_chunk *chunks, size_t n,
                             uint8_t *raw, size_t raw_len, xfg_result *res)
 {

@@ -98,9 +98,19 @@ class Reader(object):
         return capi.READ_FN(rd), capi.SEEK_FN(sk)
 
     def Reset(self, rs, ctx=None):
-        """Reset (reader.go:124): returns None or raises the parse error (the Reader stays usable for Close)."""
+        """Reset (reader.go:124): returns None or raises the parse error (the Reader stays usable for Close).
+        A bytes-like stream is read where it lies by the library (xfg_reader_new_mem), without callbacks."""
         if not (hasattr(rs, "read") and hasattr(rs, "seek")):
-            rs = io.BytesIO(bytes(rs))
+            L = capi.lib()
+            data = bytes(rs)                              # kept alive for the reader
+            if not self._h:
+                self._ctx = ctx or default_context()
+                cls = L.xfg_reader_new_mem(self._ctx.handle, data, len(data), ctypes.byref(self._h))
+            else:
+                cls = L.xfg_reader_reset_mem(self._h, data, len(data))
+            self._rs, self._cbs = data, None
+            _raise_class(cls)
+            return
         self._rs = rs
         self._cbs = self._make_callbacks(rs)
         L = capi.lib()

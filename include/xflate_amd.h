@@ -248,9 +248,19 @@ typedef struct {
  * Returns an XFG_ERR_* class.
  */
 int xfg_reader_new(xfg_ctx *ctx, xfg_read_fn rd, xfg_seek_fn sk, void *user, xfg_reader **out);
+/* xflate.NewReader(bytes.NewReader(stream), nil): the same over a stream in memory, which the caller keeps alive and
+ * unchanged until xfg_reader_free (a mapped file, say).  No callbacks: the library reads the bytes itself. */
+int xfg_reader_new_mem(xfg_ctx *ctx, const uint8_t *stream, size_t len, xfg_reader **out);
+/* Reset(bytes.NewReader(stream)) on any reader (it keeps its decode window's buffers). */
+int xfg_reader_reset_mem(xfg_reader *r, const uint8_t *stream, size_t len);
 /* xflate.(*Reader).Reset (reader.go:124). */
 int xfg_reader_reset(xfg_reader *r, xfg_read_fn rd, xfg_seek_fn sk, void *user);
-/* xflate.(*Reader).Read (reader.go:162): returns the byte count (> 0) or 0 with *err set. */
+/* xflate.(*Reader).Read (reader.go:162): returns the byte count (> 0) or 0 with *err set.
+ * How many bytes one call returns is the one thing that differs from the reference, which never returns more than
+ * the rest of the current chunk: a request of 1 MiB or more returns a run of whole chunks that decoded cleanly (one
+ * copy out of the decoded window), and a request of 32 MiB or more that needs a new window has the chunks it
+ * covers decoded straight into buf, which is then used as scratch beyond the count returned (as io.Reader allows).
+ * Bytes, offsets, and the error class after a given number of bytes are the reference's either way. */
 int64_t xfg_reader_read(xfg_reader *r, uint8_t *buf, int64_t n, int *err);
 /* xflate.(*Reader).Seek (reader.go:221): returns the new offset, or 0 with *err set. */
 int64_t xfg_reader_seek(xfg_reader *r, int64_t offset, int whence, int *err);

@@ -53,3 +53,36 @@ for it in range(5):
     assert got == total and err.value == capi.ERR_EOF, (got, err.value)
     print("xfg_reader sequential Read: %.1f MiB in %.2f ms = %.2f GB/s (%d bytes read from the source)" % (got / 2**20, dt * 1e3, got / dt / 1e9, rd.bytes_read()))
 rd.Close()
+
+ctx2 = capi.Context(0)
+# ---- the same stream read where it lies (xfg_reader_new_mem: no callbacks), 64 MiB reads
+h = ctypes.c_void_p()
+assert L.xfg_reader_new_mem(ctx2._h, stream, len(stream), ctypes.byref(h)) == 0
+for it in range(5):
+    if it:
+        assert L.xfg_reader_reset_mem(h, stream, len(stream)) == 0
+    got = 0
+    t0 = time.perf_counter()
+    while True:
+        k = L.xfg_reader_read(h, buf, len(buf), ctypes.byref(err))
+        if k <= 0:
+            break
+        got += k
+    dt = time.perf_counter() - t0
+    assert got == total and err.value == capi.ERR_EOF, (got, err.value)
+    print("xfg_reader over memory, sequential Read, 64 MiB requests: %.1f MiB in %.2f ms = %.2f GB/s" % (got / 2**20, dt * 1e3, got / dt / 1e9))
+big = ctypes.create_string_buffer(total)
+for it in range(5):
+    assert L.xfg_reader_reset_mem(h, stream, len(stream)) == 0
+    got = 0
+    t0 = time.perf_counter()
+    while True:
+        k = L.xfg_reader_read(h, big, total, ctypes.byref(err))
+        if k <= 0:
+            break
+        got += k
+    dt = time.perf_counter() - t0
+    assert got == total and err.value == capi.ERR_EOF, (got, err.value)
+    print("xfg_reader over memory, one request for everything: %.1f MiB in %.2f ms = %.2f GB/s" % (got / 2**20, dt * 1e3, got / dt / 1e9))
+L.xfg_reader_free(h)
+ctx2.close()
