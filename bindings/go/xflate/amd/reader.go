@@ -125,12 +125,32 @@ func NewReader(rs io.ReadSeeker, conf *ReaderConfig) (*Reader, error) {
 	return xr, err
 }
 
+// NewReaderMem is NewReader over a stream that lies in memory the Go runtime does not move or free -- a mapped file
+// (syscall.Mmap), C memory -- and stays valid until the Reader is freed: the library reads it where it lies, no
+// callbacks (xfg_reader_new_mem).  Do not pass memory of the Go heap: C keeps the pointer after the call returns.
+func NewReaderMem(stream unsafe.Pointer, n int, conf *ReaderConfig) (*Reader, error) {
+	dev := 0
+	if conf != nil {
+		dev = conf.Device
+	}
+	xr := new(Reader)
+	if rc := C.xfg_create(C.int(dev), &xr.ctx); rc != C.XFG_OK {
+		return nil, errorf(errors.Internal, C.GoString(C.xfg_strerror(rc)))
+	}
+	runtime.SetFinalizer(xr, (*Reader).free)
+	cls := C.xfg_reader_new_mem(xr.ctx, (*C.uint8_t)(stream), C.size_t(n), &xr.r)
+	return xr, classErr(cls)
+}
+
 // Reset mirrors (*xflate.Reader).Reset (reader.go:124-157).
 func (xr *Reader) Reset(rs io.ReadSeeker) error {
 	if xr.h != 0 {
 		xr.h.Delete()
 	}
 	xr.h = cgo.NewHandle(&rsBox{rs})
+	if xr.user == nil { // a Reader made by NewReaderMem
+		xr.user = C.malloc(C.size_t(unsafe.Sizeof(uintptr(0))))
+	}
 	*(*uintptr)(xr.user) = uintptr(xr.h)
 	rd, sk := C.xfg_read_fn(C.goXfgRead), C.xfg_seek_fn(C.goXfgSeek)
 	if xr.r == nil {
