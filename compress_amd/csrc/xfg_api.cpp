@@ -282,6 +282,17 @@ void parallel_copy(HostPool *pool, uint8_t *dst, const uint8_t *src, size_t len)
 }
 }
 
+// The events of one pipelined call: destroyed together, whichever way the call ends.
+struct EventBag {
+    std::vector<hipEvent_t> all;
+    ~EventBag() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }
+    hipError_t make(hipEvent_t *out, unsigned flags) {
+        hipError_t e = hipEventCreateWithFlags(out, flags);
+        if (e == hipSuccess) all.push_back(*out);
+        return e;
+    }
+};
+
 // A large host-to-host copy on the context's helper threads (the Reader's copy into the caller's buffer).
 extern "C" void xfg_host_copy(xfg_ctx *c, void *dst, const void *src, size_t n) {
     if (c && n >= (4u << 20) && !c->pool) c->pool = new (std::nothrow) HostPool(kCopyThreads + 1);
@@ -341,17 +352,22 @@ static int decode_pipelined(xfg_ctx *c, const uint8_t *comp, size_t comp_len, co
     if (!c->d_scratch_k) HIP_TRY(hipMalloc(&c->d_scratch_k, kLanes * xfg_scratch_bytes(c->num_cu)));
     if (!c->pool) { c->pool = new (std::nothrow) HostPool(kCopyThreads + 1); if (!c->pool) return XFG_E_NOMEM; }
     const size_t scratch_each = xfg_scratch_bytes(c->num_cu);
+    EventBag bag;
     std::vector<hipEvent_t> ev_d(ns), ev_h(ns), ev_k(nu);
     hipEvent_t ev_c;
-    for (size_t u = 0; u < nu; u++) HIP_TRY(hipEventCreateWithFlags(&ev_k[u], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
+    for (size_t u = 0; u < nu; u++) HIP_TRY(bag.make(&ev_k[u], hipEventDisableTiming));
+    HIP_TRY(bag.make(&ev_c, hipEventDisableTiming));
     for (size_t i = 0; i < ns; i++) {
-        HIP_TRY(hipEventCreateWithFlags(&ev_d[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_h[i], hipEventDisableTiming));
+        HIP_TRY(bag.make(&ev_d[i], hipEventDisableTiming));
+        HIP_TRY(bag.make(&ev_h[i], hipEventDisableTiming));
     }
-    std::vector<hipEvent_t> tk0(nu), tk1(nu), tk2(nu);
+    std::vector<hipEvent_t> tk0(nu), tk1(nu), tk2(nu);          // XFG_PIPE_TRACE: where each unit was on the GPU's clock
     hipEvent_t tbase = nullptr;
-    if (ptrace) { for (size_t u = 0; u < nu; u++) { (void)hipEventCreate(&tk0[u]); (void)hipEventCreate(&tk1[u]); (void)hipEventCreate(&tk2[u]); } (void)hipEventCreate(&tbase); (void)hipEventRecord(tbase, c->stream); }
+    if (ptrace) {
+        for (size_t u = 0; u < nu; u++) { HIP_TRY(bag.make(&tk0[u], hipEventDefault)); HIP_TRY(bag.make(&tk1[u], hipEventDefault)); HIP_TRY(bag.make(&tk2[u], hipEventDefault)); }
+        HIP_TRY(bag.make(&tbase, hipEventDefault));
+        HIP_TRY(hipEventRecord(tbase, c->stream));
+    }
     HIP_TRY(hipMemcpyAsync(c->d_chunks, chunks, n * sizeof(xfg_chunk), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(ev_c, c->stream));
     for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(c->stream_k[k], ev_c, 0));
@@ -461,14 +477,10 @@ static int decode_pipelined(xfg_ctx *c, const uint8_t *comp, size_t comp_len, co
     for (int k = 0; k < lanes; k++) (void)hipStreamSynchronize(c->stream_k[k]);
     (void)hipStreamSynchronize(c->stream_up);
     (void)hipStreamSynchronize(c->stream_dl);
-    for (size_t i = 0; i < ns; i++) { (void)hipEventDestroy(ev_h[i]); (void)hipEventDestroy(ev_d[i]); }
-    for (size_t u = 0; u < nu; u++) (void)hipEventDestroy(ev_k[u]);
-    (void)hipEventDestroy(ev_c);
     if (ptrace)
         for (size_t u = 0; u < nu; u++) {
             float a = 0, b = 0, d = 0;
             (void)hipEventElapsedTime(&a, tbase, tk0[u]); (void)hipEventElapsedTime(&b, tbase, tk1[u]); (void)hipEventElapsedTime(&d, tbase, tk2[u]);
-            (void)hipEventDestroy(tk0[u]); (void)hipEventDestroy(tk1[u]); (void)hipEventDestroy(tk2[u]);
             fprintf(stderr, "[pipe] unit %zu lane %zu slices %zu-%zu: gpu time lane free %.2f uploads done %.2f kernel done %.2f ms\n", u, u % lanes, units[u].s0, units[u].s1, a, b, d);
         }
     if (ptrace)
