@@ -14,6 +14,7 @@ ST_OK, ST_CORRUPTED, ST_UNEXPECTED_EOF, ST_SIZE_MISMATCH, ST_NO_SYNC, ST_INTERNA
 ST_NAMES = ["ok", "corrupted", "unexpected_eof", "size_mismatch", "no_sync", "internal", "out_full"]
 # chunk flags
 CHUNK_END_BLOCK, CHUNK_SYNC, CHUNK_VERIFY, CHUNK_FOOTER, CHUNK_RFC_REP16, CHUNK_HOST_META = 1, 2, 4, 8, 16, 32
+DEFLATE_DYNAMIC = 0x100
 CHUNK_XFLATE_DEFLATE = CHUNK_END_BLOCK | CHUNK_SYNC | CHUNK_VERIFY | CHUNK_RFC_REP16
 CHUNK_XFLATE_INDEX = CHUNK_END_BLOCK | CHUNK_VERIFY | CHUNK_RFC_REP16
 CHUNK_XFLATE_FOOTER = CHUNK_END_BLOCK | CHUNK_VERIFY | CHUNK_FOOTER | CHUNK_RFC_REP16
@@ -160,9 +161,10 @@ class Context:
         check(lib().xfg_decode_device(self._h, d_comp, comp_len, d_chunks, n, d_raw, raw_len, d_res,
                                       stream or None), "xfg_decode_device")
 
-    def deflate(self, raw, chunk_size):
+    def deflate(self, raw, chunk_size, dynamic=False):
         """xfg_deflate: compress `raw` in chunks of chunk_size bytes (the last one shorter).
-        -> list of compressed chunks, each a DEFLATE stream without a final block ending in 00 00 ff ff."""
+        -> list of compressed chunks, each a DEFLATE stream without a final block ending in 00 00 ff ff.
+        dynamic: XFG_DEFLATE_DYNAMIC (two passes, Huffman codes built for the chunk)."""
         raw = bytes(raw)
         sizes = [min(chunk_size, len(raw) - o) for o in range(0, len(raw), chunk_size)] or [0]
         n = len(sizes)
@@ -170,7 +172,7 @@ class Context:
         co = ro = 0
         for i, rs in enumerate(sizes):
             b = lib().xfg_deflate_bound(rs)
-            arr[i] = Chunk(co, b, ro, rs, 0, 0)
+            arr[i] = Chunk(co, b, ro, rs, DEFLATE_DYNAMIC if dynamic else 0, 0)
             co += b
             ro += rs
         res = (Result * n)()
@@ -183,7 +185,7 @@ class Context:
             out.append(comp.raw[arr[i].comp_off:arr[i].comp_off + res[i].out_produced])
         return out
 
-    def deflate_chunks(self, chunks):
+    def deflate_chunks(self, chunks, dynamic=False):
         """xfg_deflate over chunks of any sizes (a list of bytes-like) in one launch -> list of compressed chunks."""
         n = len(chunks)
         if n == 0:
@@ -193,7 +195,7 @@ class Context:
         co = ro = 0
         for i, c in enumerate(chunks):
             b = lib().xfg_deflate_bound(len(c))
-            arr[i] = Chunk(co, b, ro, len(c), 0, 0)
+            arr[i] = Chunk(co, b, ro, len(c), DEFLATE_DYNAMIC if dynamic else 0, 0)
             co += b
             ro += len(c)
         res = (Result * n)()

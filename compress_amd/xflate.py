@@ -370,11 +370,13 @@ class GpuWriter(Writer):
     leave the GPU empty), so OutputOffset and the records lag behind InputOffset until the queue is drained --
     by a sync flush, an index, Close, or a full queue.  A sync flush inside a chunk compresses what the chunk holds
     so far as a segment of its own (every segment ends in 00 00 ff ff and starts without history: the
-    concatenation is what a DEFLATE stream with sync flushes is).  Level is ignored: the device compressor has one."""
+    concatenation is what a DEFLATE stream with sync flushes is).  Level 1 (BestSpeed) uses the fixed Huffman codes
+    in one pass; every other level has the device build codes for each chunk (XFG_DEFLATE_DYNAMIC, two passes)."""
 
     def __init__(self, wr, conf=None, ctx=None, batch_chunks=1024):
         self._ctx = ctx
         self._batch = max(1, int(batch_chunks))
+        self._dynamic = not (conf is not None and conf.Level == 1)
         Writer.__init__(self, wr, conf)
 
     def _zreset(self):
@@ -390,7 +392,7 @@ class GpuWriter(Writer):
             return
         ctx = self._ctx or default_context()
         todo = [q[0] for q in self._queue if len(q[0])]
-        comp = iter(ctx.deflate_chunks(todo))
+        comp = iter(ctx.deflate_chunks(todo, self._dynamic))
         for raw, zout, zin in self._queue:
             c = next(comp) if len(raw) else b"\x00\x00\x00\xff\xff"    # the empty stored block of a sync flush
             self._emit(c)
@@ -423,7 +425,7 @@ class GpuWriter(Writer):
             self._drain()                  # bytes leave in stream order
             if self._pend:
                 ctx = self._ctx or default_context()
-                out = ctx.deflate_chunks([bytes(self._pend)])[0]
+                out = ctx.deflate_chunks([bytes(self._pend)], self._dynamic)[0]
                 self._pend = bytearray()
             else:
                 out = b"\x00\x00\x00\xff\xff"

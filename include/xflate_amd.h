@@ -186,11 +186,16 @@ int xfg_sync(xfg_ctx *ctx);
  *   chunk i reads  raw[raw_off, raw_off + raw_size)
  *   and writes     comp[comp_off, comp_off + out_produced), out_produced <= comp_size;
  *   comp_off must be a multiple of 4 and comp_size >= xfg_deflate_bound(raw_size), else the chunk's
- *   status is XFG_ST_OUT_FULL and nothing is written for it.  flags is ignored, reserved must be 0.
+ *   status is XFG_ST_OUT_FULL and nothing is written for it.  reserved must be 0.  flags: XFG_DEFLATE_DYNAMIC
+ *   or 0; the XFG_CHUNK_* bits of the decode side are ignored.
  *   res[i].in_consumed = raw_size, res[i].out_produced = compressed bytes.
  * xfg_deflate takes host pointers and blocks; xfg_deflate_device takes device pointers (d_comp at
  * least 4-byte aligned), enqueues on hip_stream (NULL = the context's stream) and allocates nothing.
  */
+#define XFG_DEFLATE_DYNAMIC 0x100u   /* two passes over the chunk: count the symbols, build length-limited Huffman codes
+                                        for them (RFC 1951 3.2.7) and use those when they beat the fixed ones, header
+                                        included.  About half the speed, markedly smaller output on data whose bytes
+                                        are not evenly distributed. */
 size_t xfg_deflate_bound(size_t raw_size);
 int xfg_deflate(xfg_ctx *ctx, const uint8_t *raw, size_t raw_len,
                 const xfg_chunk *chunks, size_t n,

@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and libxflate_amd.so is linked against the
+# system's; whichever is loaded first serves both, and torch finds no GPU when it is not its own ("No HIP GPUs are
+# available").  Some GPU tests use torch for device buffers, so it goes first whatever subset of the tests runs.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

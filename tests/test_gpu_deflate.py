@@ -48,10 +48,11 @@ def _check_chunks(orc, raw, chunk_size, chunks):
 @pytest.mark.parametrize("size,chunk", [(0, 65536), (1, 65536), (3, 65536), (4, 65536), (5, 65536), (63, 65536),
                                         (64, 65536), (65, 65536), (300, 100), (65535, 65536), (65536, 65536),
                                         (70001, 65536), (200000, 16384), (300000, 262144)])
-def test_chunks_decode_to_the_input(ctx, orc, kind, size, chunk):
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_chunks_decode_to_the_input(ctx, orc, kind, size, chunk, dynamic):
     from compress_amd import synth
     raw = synth.GENERATORS[kind](size, 7 + size)
-    chunks = ctx.deflate(raw, chunk)
+    chunks = ctx.deflate(raw, chunk, dynamic)
     _check_chunks(orc, raw, chunk, chunks)
     from compress_amd import capi
     for piece_len, c in zip([min(chunk, size - o) for o in range(0, size, chunk)] or [0], chunks):
@@ -69,6 +70,46 @@ def test_compresses(ctx):
     twain = open(os.path.join(GOLDEN, "twain.txt"), "rb").read()
     assert ratio(twain) > 1.4
     assert ratio(synth.GENERATORS["random"](n, 5)) > 0.999 * n / (n + 5 * 4 + 5 * 4 * 2)
+
+
+def test_dynamic_codes(ctx, orc):
+    """XFG_DEFLATE_DYNAMIC: Huffman codes built per chunk (RFC 1951 3.2.7).  Never larger than the fixed coding of the
+    same tokens, much smaller where the bytes are unevenly distributed; text, the reference's corpora kinds, skewed
+    two- and one-symbol alphabets (the degenerate codes of flate/prefix.go:196-208), long runs of one length in the
+    header, every chunk decoded by zlib and the oracle."""
+    import random
+    from compress_amd import synth
+    twain = open(os.path.join(GOLDEN, "twain.txt"), "rb").read()
+    rng = random.Random(4)
+    cases = {
+        "twain": twain,
+        "digits": synth.GENERATORS["digits"](300000, 1),
+        "huffman": synth.GENERATORS["huffman"](300000, 2),
+        "repeats": synth.GENERATORS["repeats"](300000, 3),
+        "one byte": b"q",
+        "two bytes": b"ab",
+        "no match, two symbols": bytes(rng.choice(b"xy") for _ in range(4000)),
+        "all 256 bytes once": bytes(range(256)),
+        "all 256 bytes, skewed": bytes(min(255, int(rng.expovariate(0.05))) for _ in range(100000)),
+        "one distance only": b"abcdefgh" * 5000,
+        "fibonacci frequencies": b"".join(bytes([i]) * f for i, f in enumerate([1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987,
+                                                                                   1597, 2584, 4181, 6765, 10946, 17711])),
+    }
+    for name, raw in cases.items():
+        raw = bytes(raw)
+        for chunk in (65536, 4096):
+            fixed = ctx.deflate(raw, chunk, False)
+            dyn = ctx.deflate(raw, chunk, True)
+            _check_chunks(orc, raw, chunk, dyn)
+            for f, d in zip(fixed, dyn):
+                assert len(d) <= len(f), name
+    def total(raw, dynamic):
+        return sum(len(c) for c in ctx.deflate(raw, 65536, dynamic))
+    assert total(cases["digits"], True) < 0.75 * total(cases["digits"], False)
+    assert total(cases["huffman"], True) < 0.97 * len(cases["huffman"])          # the fixed codes cannot shrink this kind
+    assert total(twain, True) < 0.9 * total(twain, False)
+    # the fibonacci case needs codes deeper than 15 bits before they are limited
+    assert len(ctx.deflate(cases["fibonacci frequencies"], 65536, True)[0]) < len(cases["fibonacci frequencies"]) // 2
 
 
 def test_xflate_stream_of_gpu_chunks(ctx, orc):

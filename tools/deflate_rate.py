@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the GPU compressor (xfg_deflate_device) on the bench workloads' raw data, device-resident:
 raw GB/s in, compression ratio, and a GPU decode of the result compared with the input.
-usage: tools/deflate_rate.py [workload ...]"""
+usage: tools/deflate_rate.py [--dynamic] [workload ...]   (--dynamic: XFG_DEFLATE_DYNAMIC, codes built per chunk)"""
 import ctypes
 import os
 import sys
@@ -17,14 +17,16 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = capi.Context(0)
     L = capi.lib()
-    for w in sys.argv[1:] or ["c2"]:
+    args = [a for a in sys.argv[1:] if a != "--dynamic"]
+    flag = capi.DEFLATE_DYNAMIC if "--dynamic" in sys.argv[1:] else 0
+    for w in args or ["c2"]:
         shard = bench.build_shard(w, 0)
         n, cs, nd = shard["n"], shard["chunk_size"], shard["nd"]
         raw = b"".join(shard["made"][i % nd][0] for i in range(n))
         bound = L.xfg_deflate_bound(cs)
         descs = (capi.Chunk * n)()
         for i in range(n):
-            descs[i] = capi.Chunk(i * bound, bound, i * cs, cs, 0, 0)
+            descs[i] = capi.Chunk(i * bound, bound, i * cs, cs, flag, 0)
         d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         d_chunks = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         d_comp = torch.zeros(n * bound + 64, dtype=torch.uint8, device=dev)
@@ -76,8 +78,8 @@ def main():
                     if shown >= 6:
                         break
             print("  chunks that differ: %d" % int(neq.sum()))
-        print("%s: %d chunks x %d KiB  compress %.2f ms = %.1f GB/s raw in, ratio %.3f (zlib level 6: %.3f), round trip %s"
-              % (w, n, cs >> 10, ms, len(raw) / ms / 1e6, len(raw) / csum, len(raw) / len(shard["comp"]),
+        print("%s%s: %d chunks x %d KiB  compress %.2f ms = %.1f GB/s raw in, ratio %.3f (zlib level 6: %.3f), round trip %s"
+              % (w, " (dynamic codes)" if flag else "", n, cs >> 10, ms, len(raw) / ms / 1e6, len(raw) / csum, len(raw) / len(shard["comp"]),
                  "bit-exact" if ok else "MISMATCH"), flush=True)
     ctx.close()
 
