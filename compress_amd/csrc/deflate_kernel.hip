@@ -137,7 +137,7 @@ __device__ __forceinline__ u32 stored_size(u32 n) { return n + 5 * ((n + 65534) 
 // prefix.GenerateLengths' callers on the write side; what the reader checks is prefix.go:326-384: a complete
 // code, or the lone 1-bit code of handleDegenerateCodes, flate/prefix.go:196-208).  The used symbols are ranked
 // by the whole wave; the tree (two queues over the sorted weights), the depth count, the repair of depths beyond
-// maxbits (move leaves up until the Kraft sum fits, as zlib's gen_bitlen does) and the assignment (the rarest
+// maxbits (leaves move down a level until the Kraft sum fits, as zlib's gen_bitlen does) and the assignment (the rarest
 // symbols get the longest codes) run on lane 0: a few hundred dependent steps per block, against milliseconds
 // for the block's data.  Wave-uniform control flow; ends with a wave_sync.
 // ---------------------------------------------------------------------------
@@ -183,24 +183,22 @@ __device__ void build_lengths(WaveLds &L, u32 base, u32 n, u32 maxbits, u32 lane
             u32 bl[33];
             for (u32 b = 0; b <= 32; b++) bl[b] = 0;
             L.weight[2 * m - 2] = 0;
-            u32 overflow = 0;
             for (u32 k = 2 * m - 2; k-- > 0;) {
                 u32 d = L.weight[L.parent[k]] + 1;
                 L.weight[k] = d;
-                if (k < m) {
-                    if (d > maxbits) { d = maxbits; overflow++; }
-                    bl[d]++;
-                }
+                if (k < m) bl[d < maxbits ? d : maxbits]++;         // a leaf deeper than maxbits is counted at maxbits
             }
-            // too deep: every step moves one leaf of the deepest level that has room above it one level down and
-            // brings one of the overflowing leaves up as its sibling
-            while ((i32)overflow > 0) {
+            // Leaves pulled up to maxbits leave the code over-subscribed: by `excess`, in units of 2^-maxbits.  Every step
+            // below removes one unit: a leaf of the deepest level above maxbits that has one moves a level down and takes
+            // a leaf of level maxbits as its sibling (-2^-bits + 2 * 2^-(bits+1) - 2^-maxbits), as zlib's gen_bitlen does.
+            u32 kraft = 0;
+            for (u32 b = 1; b <= maxbits; b++) kraft += bl[b] << (maxbits - b);
+            for (u32 excess = kraft - (1u << maxbits); excess > 0; excess--) {
                 u32 bits = maxbits - 1;
                 while (bl[bits] == 0) bits--;
                 bl[bits]--;
                 bl[bits + 1] += 2;
                 bl[maxbits]--;
-                overflow -= 2;
             }
             u32 idx = 0;
             for (u32 bits = maxbits; bits >= 1; bits--)

@@ -112,6 +112,16 @@ def test_dynamic_codes(ctx, orc):
     assert len(ctx.deflate(cases["fibonacci frequencies"], 65536, True)[0]) < len(cases["fibonacci frequencies"]) // 2
 
 
+@pytest.mark.parametrize("seed", [226, 408, 474, 622, 1005, 1102, 7, 8, 9])
+def test_dynamic_codes_fuzz_cases(ctx, seed):
+    """Cases of tools/deflate_fuzz.py; the first six need the 15-bit / 7-bit length limit's repair (they came out
+    over-subscribed before it counted the Kraft excess)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import deflate_fuzz
+    deflate_fuzz.check(ctx, deflate_fuzz.make_pieces(seed))
+
+
 def test_xflate_stream_of_gpu_chunks(ctx, orc):
     """The chunks in an XFLATE stream (host index + footer): read back by the oracle's Reader and the GPU Reader,
     front to back and after a seek into the middle."""
