@@ -93,13 +93,19 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #define XFG_SEG_MID 160
 #endif
 #ifndef XFG_SEG_SHORT
-#define XFG_SEG_SHORT 128
+#define XFG_SEG_SHORT 96
 #endif
 #ifndef XFG_EXP_LONG_X4
 #define XFG_EXP_LONG_X4 6             // expansion (x4) below which a batch is followed by long segments
 #endif
 #ifndef XFG_EXP_SHORT_X4
 #define XFG_EXP_SHORT_X4 16           // expansion (x4) from which on it is followed by short ones
+#endif
+#ifndef XFG_SEG_RUN
+#define XFG_SEG_RUN 128               // segments of batches whose output is nearly all long matches or runs
+#endif
+#ifndef XFG_EXP_RUN_X4
+#define XFG_EXP_RUN_X4 256            // expansion (x4) from which on it is followed by those
 #endif
 #ifndef XFG_OUT_LDS
 #define XFG_OUT_LDS 2304
@@ -157,7 +163,7 @@ constexpr int MASK_WORDS = (SEG_MAX + 48 + 31) / 32;    // a path ends less than
 static_assert(MASK_WORDS * 64 * 4 <= OUT_LDS, "the token-start masks share the output window's LDS");
 static_assert(OUT_CAP >= 1024, "output window too small");
 static_assert(WT_BYTES > BWIN_BYTES && TOK_MIN >= SEG_MAX / 2, "one lane's tokens (>= 2 bits each) must fit the token list");
-static_assert(SEG_MIN >= 64 && (XFG_SEG_BITS || (SEG_MIN <= XFG_SEG_MID && XFG_SEG_MID <= SEG_MAX)), "segment sizes");
+static_assert(XFG_SEG_RUN >= SEG_MIN && XFG_SEG_RUN <= SEG_MAX && SEG_MIN >= 64 && (XFG_SEG_BITS || (SEG_MIN <= XFG_SEG_MID && XFG_SEG_MID <= SEG_MAX)), "segment sizes");
 static_assert(OUT_LDS <= 65536, "token destinations are 16-bit");
 
 // Table entry (u32): what one decode step does with the bits at the head of the buffer.
@@ -1444,7 +1450,8 @@ __device__ __forceinline__ u32 seg_bits_for(u32 out_bytes, u32 in_bits) {
     const u64 out_x4 = (u64)out_bytes * 32;                     // output bits times four (a whole chunk's sizes come through here too)
     if (out_x4 < (u64)XFG_EXP_LONG_X4 * in_bits) return XFG_SEG_LONG;          // below 1.5: literals dominate
     if (out_x4 < (u64)XFG_EXP_SHORT_X4 * in_bits) return XFG_SEG_MID;
-    return XFG_SEG_SHORT;                                       // 4 and more: matches dominate
+    if (out_x4 < (u64)XFG_EXP_RUN_X4 * in_bits) return XFG_SEG_SHORT;          // 4 and more: matches dominate
+    return XFG_SEG_RUN;                                         // 32 and more: a few tokens fill the window
 #endif
 }
 

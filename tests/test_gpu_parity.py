@@ -280,7 +280,7 @@ def test_generated_streams_match_oracle(ctx, orc, kind, level, strategy):
 
 @pytest.mark.parametrize("level,strategy", [(6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED)])
 def test_chunks_that_change_character(ctx, orc, level, strategy):
-    """The kernel picks its segment size (208 / 160 / 128 bits) per batch from the expansion of the batch
+    """The kernel picks its segment size (208 / 160 / 96 bits, 128 for runs) per batch from the expansion of the batch
     before it.  These chunks switch between literal-heavy, mixed and match-heavy data every few KB, also
     inside one DEFLATE block, so that every transition between sizes is taken; results must not depend on it."""
     from compress_amd import synth
