@@ -107,6 +107,9 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_EXP_RUN_X4
 #define XFG_EXP_RUN_X4 256            // expansion (x4) from which on it is followed by those
 #endif
+#ifndef XFG_RESOLVE_EXACT
+#define XFG_RESOLVE_EXACT 1           // resolve: a token waits for the pending tokens that write its source bytes, not for all before it
+#endif
 #ifndef XFG_OUT_LDS
 #define XFG_OUT_LDS 2304
 #endif
@@ -1391,6 +1394,26 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
         const i32 e = s + (i32)(len < dist ? len : dist);       // end of the source bytes other tokens may own
         bool pending = rem > 0 && !indep;
         u32 span = dist;
+#if XFG_RESOLVE_EXACT
+        // Which tokens of the round can write into this one's source bytes [s, e): destinations are disjoint and in
+        // stream order over the lanes, so they are the lanes from the first whose destination ends after s to the last
+        // whose destination starts before e (both below this lane).  Two binary searches over the lanes' values; a
+        // token is ready when none of those lanes is pending -- not only when everything before its source is done,
+        // which on match-heavy data took 2 to 2.5 times as many passes of the loop below.
+        u64 blockers = 0;
+        {
+            const u32 dst_lo = have ? d : 0x7fffffffu, dst_hi = have ? d + len : 0x7fffffffu;
+            u32 n_end = 0, n_beg = 0;                           // lanes whose destination ends at or before s / starts before e
+#pragma unroll
+            for (u32 step = 32; step >= 1; step >>= 1) {
+                const i32 pe = __builtin_amdgcn_ds_bpermute((int)((n_end + step - 1) << 2), (int)dst_hi);
+                const i32 pb = __builtin_amdgcn_ds_bpermute((int)((n_beg + step - 1) << 2), (int)dst_lo);
+                if (pe <= s) n_end += step;
+                if (pb < e) n_beg += step;
+            }
+            if (have && n_beg > n_end) blockers = (~0ull >> (64 - n_beg)) & ~((1ull << n_end) - 1);   // lanes n_end .. n_beg - 1
+        }
+#endif
         for (;;) {
             const u64 pm = __ballot(pending);
             if (pm == 0) break;
@@ -1403,7 +1426,11 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
                 wave_sync();
                 continue;
             }
+#if XFG_RESOLVE_EXACT
+            if (pending && !is_long && (pm & blockers) == 0) {
+#else
             if (pending && !is_long && e <= water) {
+#endif
                 while (rem) {
                     u32 n = span < rem ? span : rem;
                     if (n > 16) n = 16;
