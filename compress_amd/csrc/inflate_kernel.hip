@@ -107,6 +107,9 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_EXP_RUN_X4
 #define XFG_EXP_RUN_X4 256            // expansion (x4) from which on it is followed by those
 #endif
+#ifndef XFG_SPEC_WALK_ON_DYNAMIC
+#define XFG_SPEC_WALK_ON_DYNAMIC 1    // the same for dynamic blocks
+#endif
 #ifndef XFG_SPEC_WALK_ON
 #define XFG_SPEC_WALK_ON 1            // fixed blocks: a speculative walk goes on over a code that would end it
 #endif
@@ -1070,7 +1073,7 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
             }
             tokprev = m_tok;
             const u32 over = seg_bits - 1 - rel;                // negative = at or past the segment end
-            if (!CHECK && RUNIN) {
+            if (!CHECK && (RUNIN || XFG_SPEC_WALK_ON_DYNAMIC)) {
                 // keep_stop = 0: a guessed path walks on over a code that would end it (it is a guess: with the fixed codes
                 // seven zero bits read as the end of the block) and such a code counts as a token boundary for the exit
                 const u32 m_stop = (u32)__builtin_amdgcn_sbfe((int)e, 14u, 1u);
@@ -1581,7 +1584,11 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                     endA = sync_segment<false, true>(L, wb0, start, seg_start, seg_bits, lane, eA, mg);
 #endif
                 } else {
+#if XFG_SPEC_WALK_ON_DYNAMIC
+                    endA = sync_segment<false, false>(L, wb0, start, seg_start, seg_bits, lane, eA, mg, lane == 0 ? ~0u : 0u);
+#else
                     endA = sync_segment<false, false>(L, wb0, start, seg_start, seg_bits, lane, eA, mg);
+#endif
                 }
                 PROF_ADD(PF_P_SPEC, lane);
             }
