@@ -93,7 +93,7 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #define XFG_SEG_MID 160
 #endif
 #ifndef XFG_SEG_SHORT
-#define XFG_SEG_SHORT 96
+#define XFG_SEG_SHORT 80
 #endif
 #ifndef XFG_EXP_LONG_X4
 #define XFG_EXP_LONG_X4 6             // expansion (x4) below which a batch is followed by long segments
@@ -106,6 +106,9 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #endif
 #ifndef XFG_EXP_RUN_X4
 #define XFG_EXP_RUN_X4 256            // expansion (x4) from which on it is followed by those
+#endif
+#ifndef XFG_SPEC_BACK_SHORT
+#define XFG_SPEC_BACK_SHORT 96         // run-in of the speculative walk before a short (XFG_SEG_SHORT) segment, dynamic blocks
 #endif
 #ifndef XFG_SPEC_WALK_ON_DYNAMIC
 #define XFG_SPEC_WALK_ON_DYNAMIC 1    // the same for dynamic blocks
@@ -132,7 +135,7 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #define XFG_SUBBATCH 1                // 1: a batch's live lanes are written out in as many window-fulls as it takes
 #endif
 #ifndef XFG_ACCEPT_FD
-#define XFG_ACCEPT_FD 56              // settle for a verified prefix of this many lanes (64 = insist on all)
+#define XFG_ACCEPT_FD 64              // settle for a verified prefix of this many lanes (64 = insist on all)
 #endif
 constexpr int SEG_MAX = XFG_SEG_BITS ? XFG_SEG_BITS : XFG_SEG_LONG;   // the longest segment: sizes the LDS windows
 constexpr int SEG_MIN = XFG_SEG_BITS ? XFG_SEG_BITS : XFG_SEG_SHORT;
@@ -147,7 +150,7 @@ constexpr int WT_BYTES = (8 * (XFG_SEG_BITS ? XFG_SEG_BITS : XFG_SEG_MID) + 64 +
 constexpr int TOK_MIN = (WT_BYTES - BWIN_BYTES) / 6;            // tokens per round at the longest segment size
 constexpr int MAX_PASSES = 6;           // speculative passes before settling for the stable prefix (careful path)
 #ifndef XFG_MAX_FIX
-#define XFG_MAX_FIX 5
+#define XFG_MAX_FIX 7
 #endif
 #ifndef XFG_STORED_DEEP
 #define XFG_STORED_DEEP 1
@@ -228,7 +231,8 @@ __device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
 // that no other code reads.  The production build compiles all of this away.
 enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
        PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
-       PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_P_SPEC, PF_P_FIX, PF_P_COUNT, PF_N_FIX, PF_COUNTERS = 24 };
+       PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_P_SPEC, PF_P_FIX, PF_P_COUNT, PF_N_FIX,
+       PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_COUNTERS = 32 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -1567,10 +1571,13 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             u32 endA;
             {
                 PROF_T0();
-                if (spec_back) {
+                // (dynamic blocks: a run-in for the short segments of match-heavy stretches, where half of the guessed paths
+                // would not meet the true one before their segment ends)
+                const u32 back = spec_back ? spec_back : (seg_bits <= (u32)XFG_SEG_SHORT ? (u32)XFG_SPEC_BACK_SHORT : 0u);
+                if (back) {
                     // the walk starts before its segment: by the segment's first bit it has usually met the true
                     // path.  The run-in never reaches back beyond p0, a true start.
-                    start = seg_start - p0 > spec_back ? seg_start - spec_back : p0;
+                    start = seg_start - p0 > back ? seg_start - back : p0;
 #if XFG_SPEC_WALK_ON
                     // A walk from a guessed position often runs into a code that ends it: with the fixed codes the end of
                     // block is seven zero bits, and a third of all guessed starts meet that pattern (or 286 / 287 / a
@@ -1630,7 +1637,18 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             const u32 pf2 = lane_prev(sg.flag);
             const bool okc = !dead && lane < verified && (lane == 0 || (pe2 == start && pf2 == F_NONE));
             const u64 bad = ~__ballot(okc);
-            verified = bad ? (u32)__ffsll((long long)bad) - 1 : 64u;
+            PROF_CNT(PF_C_FIX_LOST, 64 - verified, lane);       // the chain of starts was not settled beyond this lane (or it ended)
+            {
+                const u32 v1 = verified;
+                verified = bad ? (u32)__ffsll((long long)bad) - 1 : 64u;
+                if (verified < v1 && verified > 0) {
+                    const bool flagged = lane_get(sg.flag, verified - 1) != F_NONE;      // the lane before the cut ended the block ...
+                    (void)flagged;
+                    PROF_CNT(flagged ? PF_C_FLAG_CUTS : PF_C_CAP_CUTS, 1, lane);         // ... or stopped at its output cap
+                    PROF_CNT(flagged ? PF_C_FLAG_LOST : PF_C_CAP_LOST, v1 - verified, lane);
+                }
+            }
+            (void)bad;
             // a token that runs past the end of the stream: decode this batch again with the end-of-input checks
             if (__ballot(lane < verified && sg.end > total_bits)) { force_tail = true; have_pf = false; continue; }
         } else {

@@ -15,7 +15,8 @@ from compress_amd import capi  # noqa: E402
 
 NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "total",
          "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens",
-         "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix"]
+         "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix",
+         "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "x29", "x30", "x31"]
 
 
 def main():
@@ -29,13 +30,13 @@ def main():
         d_raw = torch.zeros(shard["raw_len"] + 64, dtype=torch.uint8, device=dev)
         d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
         L = capi.lib()
-        buf = (ctypes.c_ulonglong * 24)()
+        buf = (ctypes.c_ulonglong * 32)()
         for it in range(2):
-            L.xfg_debug_profile(buf, 24)          # clear
+            L.xfg_debug_profile(buf, 32)          # clear
             ctx.decode_device(d_comp.data_ptr(), len(shard["comp"]), d_chunks.data_ptr(), n,
                               d_raw.data_ptr(), shard["raw_len"], d_res.data_ptr(), None)
             ctx.sync()
-        L.xfg_debug_profile(buf, 24)
+        L.xfg_debug_profile(buf, 32)
         v = {k: buf[i] for i, k in enumerate(NAMES)}
         tot = max(v["total"], 1)
         print("== %s: %d chunks" % (w, n))
@@ -50,6 +51,8 @@ def main():
         print("  resolve per batch: wait for earlier stores %.0f, pre-window sweep %.0f" % (v["r_sync"] / nb, v["r_sweep"] / nb))
         print("  batches %d  passes/batch %.2f  live lanes/batch %.1f  rounds/batch %.1f  blocks %d" %
               (v["n_batch"], v["n_pass"] / nb, v["n_live_lanes"] / nb, v["n_rounds"] / nb, v["n_blocks"]))
+        print("  lanes not kept per batch: chain not settled %.1f; cut after a lane that ended the block %.1f (%.2f cuts); after a lane at its output cap %.1f (%.2f cuts)" %
+              (v["c_fix_lost"] / nb, v["c_flag_lost"] / nb, v["c_flag_cuts"] / nb, v["c_cap_lost"] / nb, v["c_cap_cuts"] / nb))
         print("  cycles/batch: count %.0f emit %.0f resolve %.0f window %.0f; header cycles/block %.0f" %
               (v["count_passes"] / nb, v["emit_pass"] / nb, v["resolve"] / nb, v["window"] / nb,
                v["header"] / max(v["n_blocks"], 1)))
