@@ -107,6 +107,12 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #ifndef XFG_EXP_RUN_X4
 #define XFG_EXP_RUN_X4 256            // expansion (x4) from which on it is followed by those
 #endif
+#ifndef XFG_SPEC_BACK_MID
+#define XFG_SPEC_BACK_MID 0
+#endif
+#ifndef XFG_SPEC_BACK_LONG
+#define XFG_SPEC_BACK_LONG 0
+#endif
 #ifndef XFG_SPEC_BACK_SHORT
 #define XFG_SPEC_BACK_SHORT 96         // run-in of the speculative walk before a short (XFG_SEG_SHORT) segment, dynamic blocks
 #endif
@@ -1573,7 +1579,9 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 PROF_T0();
                 // (dynamic blocks: a run-in for the short segments of match-heavy stretches, where half of the guessed paths
                 // would not meet the true one before their segment ends)
-                const u32 back = spec_back ? spec_back : (seg_bits <= (u32)XFG_SEG_SHORT ? (u32)XFG_SPEC_BACK_SHORT : 0u);
+                const u32 back = spec_back ? spec_back : seg_bits <= (u32)XFG_SEG_SHORT ? (u32)XFG_SPEC_BACK_SHORT :
+                                 seg_bits == (u32)XFG_SEG_MID ? (u32)XFG_SPEC_BACK_MID :
+                                 seg_bits == (u32)XFG_SEG_LONG ? (u32)XFG_SPEC_BACK_LONG : 0u;
                 if (back) {
                     // the walk starts before its segment: by the segment's first bit it has usually met the true
                     // path.  The run-in never reaches back beyond p0, a true start.
