@@ -238,7 +238,7 @@ __device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
 enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
        PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
        PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_P_SPEC, PF_P_FIX, PF_P_COUNT, PF_N_FIX,
-       PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_COUNTERS = 32 };   // lanes a batch did not keep, by cause
+       PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB, PF_COUNTERS = 32 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -438,6 +438,9 @@ __device__ __forceinline__ u32 reader_bitpos(const Reader &r) { return r.bytepos
 template <int TYPE, int ROOT, int TAB_OFF>
 __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane) {
     // 1. histogram of code lengths
+#ifdef XFG_PROFILE
+    const unsigned long long bt0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (lane < 16) L.h.cnt[lane] = 0;
     wave_sync();
     for (u32 i = lane; i < n; i += 64) {
@@ -480,6 +483,7 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
         for (int l = 1; l <= 15; l++) {
             code <<= 1;
             run[l] = off;
+
             if (lane == 0) {
                 L.h.first[l] = code;
                 L.h.offs[l] = off;
@@ -505,6 +509,10 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
     }
     if (degenerate && lane == 0) L.h.sorted[1] = 0xffff;          // the out-of-range sibling
     wave_sync();
+#ifdef XFG_PROFILE
+    const unsigned long long bt1_ = __builtin_amdgcn_s_memtime();
+    if (TYPE == T_LIT && lane == 0) L.prof[PF_T_SORT] += bt1_ - bt0_;
+#endif
 
     // 4. root table.  u runs over ROOT-bit code space MSB-first; the table is indexed LSB-first.
     //    Codes of length l <= ROOT own [endr[l-1], endr[l]) there; whatever lies at or beyond
@@ -518,6 +526,10 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
         tab[__brev(u) >> (32 - ROOT)] = sym_entry(TYPE, sym, l);
     }
 
+#ifdef XFG_PROFILE
+    const unsigned long long bt2_ = __builtin_amdgcn_s_memtime();
+    if (TYPE == T_LIT && lane == 0) L.prof[PF_T_ROOT] += bt2_ - bt1_;
+#endif
     // 5. sub-tables for code words longer than ROOT: one per ROOT-bit prefix u >= end_root,
     //    sized by the longest code under that prefix (as zlib's inftrees does).
     if (maxlen > (u32)ROOT) {
@@ -559,6 +571,9 @@ __device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane
         }
     }
     wave_sync();
+#ifdef XFG_PROFILE
+    if (TYPE == T_LIT && lane == 0) L.prof[PF_T_SUB] += __builtin_amdgcn_s_memtime() - bt2_;
+#endif
     return 0;
 }
 

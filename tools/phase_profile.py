@@ -16,7 +16,7 @@ from compress_amd import capi  # noqa: E402
 NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "total",
          "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens",
          "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix",
-         "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "x29", "x30", "x31"]
+         "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "t_sort", "t_root", "t_sub"]
 
 
 def main():
@@ -45,6 +45,8 @@ def main():
         blk = max(v["n_blocks"], 1)
         print("  header per block: clen table %.0f, lengths loop %.0f, lit table %.0f, dist table %.0f" %
               (v["h_clen_table"] / blk, v["h_lens_loop"] / blk, v["h_lit_table"] / blk, v["h_dist_table"] / blk))
+        print("  literal/length table per block: histogram + canonical order %.0f, root table %.0f, second-level tables %.0f" %
+              (v["t_sort"] / blk, v["t_root"] / blk, v["t_sub"] / blk))
         nb = max(v["n_batch"], 1)
         print("  walks per batch: speculative %.0f, re-synchronisation %.0f (%.2f walks), count %.0f cycles" %
               (v["p_spec"] / nb, v["p_fix"] / nb, v["n_fix"] / nb, v["p_count"] / nb))
