@@ -238,7 +238,8 @@ __device__ __forceinline__ u32 sym_entry(int type, u32 sym, u32 nbits) {
 enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TOTAL,
        PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
        PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_P_SPEC, PF_P_FIX, PF_P_COUNT, PF_N_FIX,
-       PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB, PF_COUNTERS = 32 };   // lanes a batch did not keep, by cause
+       PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB,
+       PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_COUNTERS = 40 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -274,6 +275,22 @@ struct TokList {
     u16 *tdst;          // their destinations in the output window
     u32 max;            // tokens per round
 };
+// Positions in the output window (token destinations, orel, woff) count bytes from the start of L.win, which the
+// union follows without a gap: the window is at OUT_POS unless a round moves the border between its token list
+// and its output (decode_huffman_block).  The 64 bytes from DUMP_POS on are written and never read.
+constexpr u32 OUT_POS = WT_BYTES;
+constexpr u32 DUMP_POS = WT_BYTES + OUT_LDS + 16;
+static_assert(offsetof(WaveLds, out) == offsetof(WaveLds, win) + WT_BYTES && WT_BYTES % 16 == 0 && offsetof(WaveLds, win) % 16 == 0,
+              "the output window follows the token list, 16-byte aligned");
+static_assert(DUMP_POS + 64 <= WT_BYTES + sizeof(((WaveLds *)nullptr)->out), "dump bytes lie inside the window's slack");
+__device__ __forceinline__ TokList token_list_n(WaveLds &L, u32 seg_bits, u32 max) {
+    const u32 bwin = 8 * seg_bits + 64;
+    TokList t;
+    t.max = max;
+    t.tok = reinterpret_cast<u32 *>(reinterpret_cast<u8 *>(L.win) + bwin);
+    t.tdst = reinterpret_cast<u16 *>(t.tok + t.max);
+    return t;
+}
 __device__ __forceinline__ TokList token_list(WaveLds &L, u32 seg_bits) {
     const u32 bwin = 8 * seg_bits + 64;
     TokList t;
@@ -893,7 +910,7 @@ __device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, const TokList tl,
 {
     const u32 *win = reinterpret_cast<const u32 *>(L.win);
     const u32 tab_lds = (u32)(uintptr_t)(const __attribute__((address_space(3))) u32 *)L.tab;
-    u8 *outw = reinterpret_cast<u8 *>(L.out);
+    u8 *outw = reinterpret_cast<u8 *>(L.win);               // positions count from the start of L.win
     u32 wp = (u32)((i32)(start >> 3) - wb0);
     u64 buf = win_load64(win, wp) >> (start & 7);
     u32 cnt = 56 - (start & 7);                                 // account 7 of the 8 bytes: cnt stays below 64
@@ -972,7 +989,7 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
     const u32 tab0 = (u32)(uintptr_t)(lds_cu32p)L.tab;
     const u32 tab1 = tab0 + 4u * LIT_TAB;
     const u32 win0 = (u32)(uintptr_t)(lds_cu8p)reinterpret_cast<const u8 *>(L.win);
-    u8 *outw = reinterpret_cast<u8 *>(L.out);
+    u8 *outw = reinterpret_cast<u8 *>(L.win);               // positions count from the start of L.win
     u32 wp = win0 + (u32)((i32)(start >> 3) - wb0);
     u64 nextw;
     nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
@@ -1003,7 +1020,7 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
             const u32 m_tok = (u32)__builtin_amdgcn_sbfe((int)e, 15u, 1u);
             if (EMIT) {
                 // a literal goes to its place; every other step writes a byte nobody reads
-                outw[(m_lit & (orel + nout)) | (~m_lit & ((u32)OUT_LDS + 16 + lane))] = (u8)val;
+                outw[(m_lit & (orel + nout)) | (~m_lit & ((u32)DUMP_POS + lane))] = (u8)val;
                 if (m_dist) {
                     const u32 dst = obase + nout;
                     const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;  // dictDecoder.HistSize
@@ -1367,7 +1384,7 @@ __device__ __forceinline__ u32 pre_compact(const TokList tl, const PreLoad &p, b
 // are not copied by their lane: when such a token is the first unresolved one, the whole wave
 // copies it (copy_long_match).
 __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveLds &L, const TokList tl, u32 M, u32 lane) {
-    u8 *outw = reinterpret_cast<u8 *>(L.out);
+    u8 *outw = reinterpret_cast<u8 *>(L.win);               // positions count from the start of L.win
     const u8 *gwin = raw + base - woff;                         // HBM address of window position 0
     u32 rounds = 0;
     const bool swept = cap >= 8;                                // pre_load may read the chunk's first 8 bytes
@@ -1573,7 +1590,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             dead = lane != 0;
             start = p0;
             // (alone, its offsets are known: this walk is the emit pass already)
-            if (!dead) sg = decode_segment_fast<true>(L, tl, wb0, start, seg_end, woff, o.pos, 0, lane, err_out);
+            if (!dead) sg = decode_segment_fast<true>(L, tl, wb0, start, seg_end, OUT_POS + woff, o.pos, 0, lane, err_out);
             emitted = true;
             wave_sync();
             PROF_CNT(PF_N_PASS, 1, lane);
@@ -1708,8 +1725,15 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
         u32 lflag = F_NONE, lend = p0;
         for (u32 b0 = 0;;) {
             const u32 rel = rel0 - lane_get(rel0, b0), moff = moff0 - lane_get(moff0, b0);   // (wraps below b0: those lanes are not kept)
-            const bool keep = live && lane >= b0 && rel + sg.nout <= (u32)OUT_LDS && moff + sg.nmatch <= tl.max;
-            u32 nkeep = (u32)__popcll(__ballot(keep));          // >= 1: one lane always fits
+            // The token list and the output window share the LDS behind the compressed window: a round of many short
+            // matches moves the border up, a round of long ones down (six bytes per token, and the list's length is
+            // rounded up to eight tokens so that the window stays 16-byte aligned).  One lane always fits:
+            // <= SEG_MAX / 2 tokens and < OUT_LDS bytes.  (A batch that lane 0 has emitted already used the fixed border.)
+            const u32 room = (u32)(WT_BYTES + OUT_LDS) - (8 * seg_bits + 64);
+            const bool keep = live && lane >= b0 &&
+                              (emitted ? rel + sg.nout <= (u32)OUT_LDS && moff + sg.nmatch <= tl.max
+                                       : 6 * (moff + sg.nmatch + 7) + rel + sg.nout <= room);
+            u32 nkeep = (u32)__popcll(__ballot(keep));          // >= 1
 #if !XFG_SUBBATCH
             const bool final = true;
 #else
@@ -1720,8 +1744,17 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             u32 M = lane_get(moff + sg.nmatch, lastl);
             lflag = lane_get(sg.flag, lastl);
             lend = lane_get(sg.end, lastl);
-            const u32 wo = (u32)((uintptr_t)(o.raw + o.pos) & 15);    // window position of the round's first byte
+            const u32 wo = (u32)((uintptr_t)(o.raw + o.pos) & 15);    // the round's first byte in the window: its HBM address mod 16
+            const u32 tmax = emitted ? tl.max : (M + 7) & ~7u;
+            const TokList tlr = token_list_n(L, seg_bits, tmax);
+            const u32 ob = emitted ? OUT_POS : 8 * seg_bits + 64 + 6 * tmax;   // where the window starts, from L.win
             PROF_CNT(PF_N_LIVE, nkeep, lane);
+            PROF_CNT(PF_N_WFULL, 1, lane);
+            if (!final) {                                       // what kept the next lane out: the token list or the output window
+                const bool by_tok = 6 * lane_get(moff + sg.nmatch, b0 + nkeep) > lane_get(rel + sg.nout, b0 + nkeep);
+                (void)by_tok;
+                PROF_CNT(by_tok ? PF_N_WF_TOK : PF_N_WF_OUT, 1, lane);
+            }
             if (b0 == 0) {
 #if XFG_SUBBATCH
                 want = 64;
@@ -1748,8 +1781,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
             {
                 PROF_T0();
                 if (keep && !emitted) {
-                    if (tail) fin = decode_segment_tail<true>(L, tl, wb0, start, seg_end, total_bits, dist_empty, wo + rel, o.pos + rel, moff, err_out);
-                    else      fin = decode_segment_fast<true>(L, tl, wb0, start, seg_end, wo + rel, o.pos + rel, moff, lane, err_out);
+                    if (tail) fin = decode_segment_tail<true>(L, tlr, wb0, start, seg_end, total_bits, dist_empty, ob + wo + rel, o.pos + rel, moff, err_out);
+                    else      fin = decode_segment_fast<true>(L, tlr, wb0, start, seg_end, ob + wo + rel, o.pos + rel, moff, lane, err_out);
                 }
                 wave_sync();
                 PROF_ADD(PF_EMIT, lane);
@@ -1769,7 +1802,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 PROF_T0();
                 mem_sync();                                     // earlier rounds' flushed bytes are read back here
                 PROF_ADD(PF_R_SYNC, lane);
-                resolve_tokens(o.raw, o.cap, o.pos, wo, L, tl, M, lane);
+                resolve_tokens(o.raw, o.cap, o.pos, ob + wo, L, tlr, M, lane);
                 PROF_ADD(PF_RESOLVE, lane);
             }
             // ---- flush to HBM (never beyond the chunk's capacity)
@@ -1778,7 +1811,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
                 u32 nflush = total_out;
                 if (o.pos >= o.cap) nflush = 0; else if (nflush > o.cap - o.pos) nflush = o.cap - o.pos;
                 wave_sync();
-                flush_output(o.raw, o.pos, reinterpret_cast<const u8 *>(L.out), wo, nflush, lane);
+                flush_output(o.raw, o.pos, reinterpret_cast<const u8 *>(L.win), ob + wo, nflush, lane);
                 wave_sync();
                 PROF_ADD(PF_FLUSH, lane);
             }

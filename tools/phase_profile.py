@@ -16,7 +16,8 @@ from compress_amd import capi  # noqa: E402
 NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "total",
          "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens",
          "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix",
-         "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "t_sort", "t_root", "t_sub"]
+         "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "t_sort", "t_root", "t_sub",
+         "n_wfull", "n_wf_tok", "n_wf_out"]
 
 
 def main():
@@ -30,13 +31,13 @@ def main():
         d_raw = torch.zeros(shard["raw_len"] + 64, dtype=torch.uint8, device=dev)
         d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
         L = capi.lib()
-        buf = (ctypes.c_ulonglong * 32)()
+        buf = (ctypes.c_ulonglong * 40)()
         for it in range(2):
-            L.xfg_debug_profile(buf, 32)          # clear
+            L.xfg_debug_profile(buf, 40)          # clear
             ctx.decode_device(d_comp.data_ptr(), len(shard["comp"]), d_chunks.data_ptr(), n,
                               d_raw.data_ptr(), shard["raw_len"], d_res.data_ptr(), None)
             ctx.sync()
-        L.xfg_debug_profile(buf, 32)
+        L.xfg_debug_profile(buf, 40)
         v = {k: buf[i] for i, k in enumerate(NAMES)}
         tot = max(v["total"], 1)
         print("== %s: %d chunks" % (w, n))
@@ -55,6 +56,8 @@ def main():
               (v["n_batch"], v["n_pass"] / nb, v["n_live_lanes"] / nb, v["n_rounds"] / nb, v["n_blocks"]))
         print("  lanes not kept per batch: chain not settled %.1f; cut after a lane that ended the block %.1f (%.2f cuts); after a lane at its output cap %.1f (%.2f cuts)" %
               (v["c_fix_lost"] / nb, v["c_flag_lost"] / nb, v["c_flag_cuts"] / nb, v["c_cap_lost"] / nb, v["c_cap_cuts"] / nb))
+        print("  window-fulls per batch %.2f (cut by the token list %.2f, by the output window %.2f); match tokens per batch %.0f" %
+              (v["n_wfull"] / nb, v["n_wf_tok"] / nb, v["n_wf_out"] / nb, v["n_tokens"] / nb))
         print("  cycles/batch: count %.0f emit %.0f resolve %.0f window %.0f; header cycles/block %.0f" %
               (v["count_passes"] / nb, v["emit_pass"] / nb, v["resolve"] / nb, v["window"] / nb,
                v["header"] / max(v["n_blocks"], 1)))
