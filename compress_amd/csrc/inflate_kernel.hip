@@ -5,8 +5,8 @@
 // CUs' LDS); every wave draws its next chunk from a counter, expensive chunks first.
 //
 // Inside a Huffman block the 64 lanes work on 64 consecutive segments of the bit stream
-// at once (decode_huffman_block), one "batch" per iteration; the segment size (128, 160 or
-// 208 bits) is chosen per batch from the expansion of the batch before it (seg_bits_for):
+// at once (decode_huffman_block), one "batch" per iteration; the segment size (80, 128, 160 or
+// 240 bits) is chosen per batch from the expansion of the batch before it (seg_bits_for):
 //   stage 1  a. speculative walk: lane i starts at segment boundary i, which is almost
 //               never a code-word boundary, and marks every bit position where one of
 //               its tokens starts (sync_segment<false>).  Prefix codes self-synchronise,
@@ -24,7 +24,8 @@
 //            root and second-level tables share the instruction stream: a small
 //            per-lane state machine), from a 64-bit register bit buffer that is topped
 //            up from the LDS copy of the compressed window.  The verified lanes are then
-//            emitted, resolved and flushed one window-full at a time (rounds).  Stretches
+//            emitted, resolved and flushed one window-full at a time (rounds); the token list and
+//            the output window share their LDS, and every round sets the border between them.  Stretches
 //            where one lane's tokens fill the window are decoded by lane 0 alone (serial batches).
 //   stage 2  match resolution (resolve_tokens): sources before the window come from
 //            HBM/L2, four rounds of 64 tokens in flight; what is left is resolved 64
@@ -87,7 +88,7 @@ constexpr int MAX_HIST = 32768;         // flate/common.go:16
 #define XFG_SEG_BITS 0
 #endif
 #ifndef XFG_SEG_LONG
-#define XFG_SEG_LONG 208
+#define XFG_SEG_LONG 240
 #endif
 #ifndef XFG_SEG_MID
 #define XFG_SEG_MID 160
