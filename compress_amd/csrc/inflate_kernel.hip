@@ -1067,7 +1067,16 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
     const u32 tab0 = (u32)(uintptr_t)(lds_cu32p)L.tab;
     const u32 tab1 = tab0 + 4u * LIT_TAB;
     const u32 win0 = (u32)(uintptr_t)(lds_cu8p)reinterpret_cast<const u8 *>(L.win);
-    u32 *mrow = L.mask + lane;
+    // the lane's mask word for position rel, as an LDS byte address: word (rel >> 5) of lane l is at [w * 64 + l]
+    typedef __attribute__((address_space(3))) u32 *lds_u32p;
+    // (a shift and a shift-add; the compiler's own form of the same address is shift, and, add)
+    const u32 mbase = (u32)(uintptr_t)(lds_cu32p)L.mask + (lane << 2);
+    auto mrow_addr = [mbase](u32 rel_) { u32 a; asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a) : "v"(rel_ >> 5), "v"(mbase)); return a; };
+#define MROW(rel_) ((lds_u32p)(uintptr_t)mrow_addr(rel_))
+    // (opaque to the compiler: as a comparison of the lane number it would live in a scalar register pair,
+    // which is spilled and reloaded in every step)
+    asm volatile("" : "+v"(keep_stop));
+    const u32 ks_sign = keep_stop | ~(u32)E_SIGN, ks_inv = ~keep_stop;
     u32 wp = win0 + (u32)((i32)(start >> 3) - wb0);
     u64 nextw;
     nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
@@ -1079,7 +1088,7 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
     u32 tb = tab0, tw = LIT_ROOT;
     u32 e = 0, hit = 0;
     u32 tokprev = ~0u;                                          // the walk starts at a token boundary
-    if (!CHECK && (i32)rel >= 0) mrow[(rel >> 5) << 6] = 1u << (rel & 31);   // rows were cleared: a plain store
+    if (!CHECK && (i32)rel >= 0) *MROW(rel) = 1u << (rel & 31);   // rows were cleared: a plain store
     for (;;) {
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
@@ -1090,7 +1099,7 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
             const u32 lo = (u32)buf;
             e = *(lds_cu32p)(uintptr_t)(tb + (__builtin_amdgcn_ubfe(lo, 0u, tw) << 2));
             if (CHECK) {
-                const u32 w = mrow[(rel >> 5) << 6];
+                const u32 w = *MROW(rel);
                 hit = (w >> (rel & 31)) & tokprev & 1u;
             }
             const u32 take = e & 31, xb = __builtin_amdgcn_ubfe(e, 5u, 5u), val = e >> 16;
@@ -1109,9 +1118,9 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
                 if (RUNIN) {
                     const u32 in_seg = ~(u32)((i32)rel >> 31);
                     const u32 rc = rel & in_seg;
-                    atomicOr(&mrow[(rc >> 5) << 6], m_tok & in_seg & (1u << (rc & 31)));
+                    __hip_atomic_fetch_or(MROW(rc), m_tok & in_seg & (1u << (rc & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 } else {
-                    atomicOr(&mrow[(rel >> 5) << 6], m_tok & (1u << (rel & 31)));
+                    __hip_atomic_fetch_or(MROW(rel), m_tok & (1u << (rel & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
             tokprev = m_tok;
@@ -1120,14 +1129,15 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
                 // keep_stop = 0: a guessed path walks on over a code that would end it (it is a guess: with the fixed codes
                 // seven zero bits read as the end of the block) and such a code counts as a token boundary for the exit
                 const u32 m_stop = (u32)__builtin_amdgcn_sbfe((int)e, 14u, 1u);
-                const u32 m_end = m_tok | (m_stop & ~keep_stop);
-                if ((i32)((over & m_end) | (e & (keep_stop | ~(u32)E_SIGN))) < 0) goto out;
+                const u32 m_end = m_tok | (m_stop & ks_inv);
+                if ((i32)((over & m_end) | (e & ks_sign)) < 0) goto out;
             } else {
                 if ((i32)((over & m_tok) | e) < 0) goto out;
             }
         }
     }
 out:
+#undef MROW
     e_out = e;
     merged = CHECK && hit != 0;
     return seg_start + rel;
@@ -2041,7 +2051,9 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, u64 comp_len, const xfg_chunk
                       u32 *__restrict__ scratch)
 {
     __shared__ WaveLds lds[WAVES_PER_BLOCK];
-    const u32 wave = uni(threadIdx.x >> 6);
+    // (one wave per workgroup: every LDS address is then a compile-time constant, which saves an add or a move per
+    // table lookup and a scalar register)
+    const u32 wave = WAVES_PER_BLOCK == 1 ? 0u : uni(threadIdx.x >> 6);
     const u32 lane = threadIdx.x & 63;
     WaveLds &L = lds[wave];
 #ifdef XFG_PROFILE
