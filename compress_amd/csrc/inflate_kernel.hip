@@ -1021,7 +1021,7 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
             const u32 m_tok = (u32)__builtin_amdgcn_sbfe((int)e, 15u, 1u);
             if (EMIT) {
                 // a literal goes to its place; every other step writes a byte nobody reads
-                outw[(m_lit & (orel + nout)) | (~m_lit & ((u32)DUMP_POS + lane))] = (u8)val;
+                outw[SEL(m_lit, orel + nout, (u32)DUMP_POS + lane)] = (u8)val;
                 if (m_dist) {
                     const u32 dst = obase + nout;
                     const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;  // dictDecoder.HistSize
