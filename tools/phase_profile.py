@@ -58,9 +58,9 @@ def main():
               (v["c_fix_lost"] / nb, v["c_flag_lost"] / nb, v["c_flag_cuts"] / nb, v["c_cap_lost"] / nb, v["c_cap_cuts"] / nb))
         print("  window-fulls per batch %.2f (cut by the token list %.2f, by the output window %.2f); match tokens per batch %.0f" %
               (v["n_wfull"] / nb, v["n_wf_tok"] / nb, v["n_wf_out"] / nb, v["n_tokens"] / nb))
-        print("  cycles/batch: count %.0f emit %.0f resolve %.0f window %.0f; header cycles/block %.0f" %
-              (v["count_passes"] / nb, v["emit_pass"] / nb, v["resolve"] / nb, v["window"] / nb,
-               v["header"] / max(v["n_blocks"], 1)))
+        print("  cycles/batch: count %.0f emit %.0f resolve %.0f flush %.0f window %.0f, all %.0f; header cycles/block %.0f" %
+              (v["count_passes"] / nb, v["emit_pass"] / nb, v["resolve"] / nb, v["flush"] / nb, v["window"] / nb,
+               v["total"] / nb, v["header"] / max(v["n_blocks"], 1)))
         ctx.close()
 
 
