@@ -240,7 +240,7 @@ enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TO
        PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
        PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_P_SPEC, PF_P_FIX, PF_P_COUNT, PF_N_FIX,
        PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB,
-       PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_COUNTERS = 40 };   // lanes a batch did not keep, by cause
+       PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_N_LONG, PF_N_LONG_G, PF_T_LONG, PF_N_INDEP, PF_COUNTERS = 40 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -1224,6 +1224,38 @@ __device__ __forceinline__ void copy16_g2l(u8 *dst, const u8 *src, u32 n) {
 // of the same bytes and the 64 lanes need no ordering among themselves.
 __device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 woff, u32 d, u32 len, u32 dist, u32 lane) {
     const i32 s = (i32)d - (i32)dist;
+    if (s >= (i32)woff) {                                       // wave-uniform
+        // The whole source lies in the window (19 of 20 long matches on match-heavy data): LDS reads only.  Below, a
+        // lane's source byte may be in the window or before it, and the choice between the two address spaces per
+        // lane makes every load a flat one, at several times an LDS read's latency.
+        if (dist >= len || dist == 1) {
+            const u32 nw = len >> 2, nt = len & 3;
+            const bool rep1 = dist == 1;
+            u32 w = 0, t = 0;
+            if (rep1) { w = outw[s] * 0x01010101u; t = w; }
+            else {
+                if (lane < nw) w = lds_load32(outw + s + 4 * lane);
+                if (lane < nt) t = outw[s + (i32)((len & ~3u) + lane)];
+            }
+            if (lane < nw) lds_store32(outw + d + 4 * lane, w);
+            if (lane < nt) outw[d + (len & ~3u) + lane] = (u8)t;
+            return;
+        }
+        const u32 rcp = ((1u << 20) + dist - 1) / dist;
+        u8 b[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const u32 j = lane + 64u * i;
+            b[i] = 0;
+            if (j < len) b[i] = outw[s + (i32)(j - ((j * rcp) >> 20) * dist)];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const u32 j = lane + 64u * i;
+            if (j < len) outw[d + j] = b[i];
+        }
+        return;
+    }
     if (dist >= len || dist == 1) {                             // wave-uniform
         // No wrap inside the match (or one byte repeated): a dword per lane, then the last len mod 4 bytes.
         const u32 nw = len >> 2, nt = len & 3;
@@ -1453,6 +1485,7 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
         {
             const u64 im = __ballot(indep);
             if (im) {
+                PROF_CNT(PF_N_INDEP, (u32)__popcll(im), lane);
                 copy_independent_long(outw, gwin, im, d, len, dist, lane);
                 wave_sync();
             }
@@ -1488,9 +1521,19 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
             const u32 first = (u32)__ffsll((long long)pm) - 1;
             const i32 water = (i32)lane_get(d, first);          // everything below is final
             if (lane_get((u32)is_long, first)) {                 // wave-uniform
+#ifdef XFG_PROFILE
+                const unsigned long long tl0_ = __builtin_amdgcn_s_memtime();
+#endif
                 copy_long_match(outw, gwin, woff, (u32)water, lane_get(len, first), lane_get(dist, first), lane);
                 if (lane == first) pending = false;
                 wave_sync();
+#ifdef XFG_PROFILE
+                if (lane == 0) {
+                    L.prof[PF_T_LONG] += __builtin_amdgcn_s_memtime() - tl0_;
+                    L.prof[PF_N_LONG] += 1;
+                    if (water - (i32)lane_get(dist, first) < (i32)woff) L.prof[PF_N_LONG_G] += 1;
+                }
+#endif
                 continue;
             }
 #if XFG_RESOLVE_EXACT

@@ -297,6 +297,35 @@ def test_chunks_that_change_character(ctx, orc, level, strategy):
     _roundtrip(ctx, orc, stream, b"".join(raws))
 
 
+@pytest.mark.parametrize("level,strategy", [(9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED)])
+def test_periodic_long_matches_every_distance(ctx, orc, level, strategy):
+    """dictDecoder's overlapping forward copy (flate/dict_decoder.go:93-100) for every period: a pattern of p bytes
+    repeated for 70 to 600 bytes is one literal run and matches of distance p, most of them long ones (which the
+    whole wave copies, byte j from source byte j mod p), for every p from 1 to 300, at every offset of the
+    window, sources inside and before it; a second pass uses periods up to 32768."""
+    rng = random.Random(level)
+    raws = []
+    for rep in range(3):
+        out = bytearray()
+        for p_ in list(range(1, 301)) + [rng.randrange(301, 32769) for _ in range(20)]:
+            pat = bytes(rng.randrange(256) for _ in range(min(p_, 4096)))
+            if p_ > len(pat):
+                pat = pat + bytes(rng.randrange(256) for _ in range(p_ - len(pat)))
+            n = rng.randrange(70, 600) + p_
+            out += (pat * (n // p_ + 1))[:n]
+            out += bytes(rng.randrange(256) for _ in range(rng.randrange(0, 9)))
+        raws.append(bytes(out))
+    comps = [synth_deflate(r, level, strategy) for r in raws]
+    from compress_amd import synth
+    stream = synth.assemble_stream(comps, [len(r) for r in raws], index_size=2)
+    _roundtrip(ctx, orc, stream, b"".join(raws))
+
+
+def synth_deflate(raw, level, strategy):
+    from compress_amd import synth
+    return synth.deflate_chunk(raw, level, strategy)
+
+
 def test_twain_default_chunks(ctx, orc):
     """BASELINE config C1: twain.txt, default 256 KiB chunk size (chunks of 262144 + 125825 bytes)."""
     from compress_amd import xflate, capi
