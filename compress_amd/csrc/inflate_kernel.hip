@@ -169,7 +169,7 @@ constexpr int MAX_PASSES = 6;           // speculative passes before settling fo
 #define XFG_MAX_FIX_FIXED 12          // fixed blocks: every walk adds about two lanes to the chain, and costs less than a new batch
 #endif
 #ifndef XFG_LONG_MATCH
-#define XFG_LONG_MATCH 64
+#define XFG_LONG_MATCH 32
 #endif
 constexpr int LONG_MATCH = XFG_LONG_MATCH;   // matches this long are copied by the whole wave, one at a time
 constexpr int SERIAL_ENTER = 6;         // a parallel batch that keeps this few lanes switches the block to serial batches
