@@ -240,7 +240,7 @@ enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TO
        PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
        PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_P_SPEC, PF_P_FIX, PF_P_COUNT, PF_N_FIX,
        PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB,
-       PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_N_LONG, PF_N_LONG_G, PF_T_LONG, PF_N_INDEP, PF_COUNTERS = 40 };   // lanes a batch did not keep, by cause
+       PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_N_LONG, PF_N_LONG_G, PF_T_LONG, PF_N_INDEP, PF_N_LONG_RDY, PF_COUNTERS = 40 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -1528,6 +1528,10 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
                 if (lane == first) pending = false;
                 wave_sync();
 #ifdef XFG_PROFILE
+                {
+                    const u64 rdy = __ballot(pending && is_long && (pm & blockers) == 0);   // other long matches that could go now
+                    if (lane == 0) L.prof[PF_N_LONG_RDY] += (unsigned long long)__popcll(rdy);
+                }
                 if (lane == 0) {
                     L.prof[PF_T_LONG] += __builtin_amdgcn_s_memtime() - tl0_;
                     L.prof[PF_N_LONG] += 1;

@@ -17,7 +17,7 @@ NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "
          "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens",
          "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix",
          "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "t_sort", "t_root", "t_sub",
-         "n_wfull", "n_wf_tok", "n_wf_out", "n_long", "n_long_g", "t_long", "n_indep"]
+         "n_wfull", "n_wf_tok", "n_wf_out", "n_long", "n_long_g", "t_long", "n_indep", "n_long_rdy"]
 
 
 def main():
@@ -58,8 +58,8 @@ def main():
               (v["c_fix_lost"] / nb, v["c_flag_lost"] / nb, v["c_flag_cuts"] / nb, v["c_cap_lost"] / nb, v["c_cap_cuts"] / nb))
         print("  window-fulls per batch %.2f (cut by the token list %.2f, by the output window %.2f); match tokens per batch %.0f" %
               (v["n_wfull"] / nb, v["n_wf_tok"] / nb, v["n_wf_out"] / nb, v["n_tokens"] / nb))
-        print("  long matches per batch: %.1f copied one at a time (%.1f with source bytes before the window), %.0f cycles each; %.1f independent ones, four at a time" %
-              (v["n_long"] / nb, v["n_long_g"] / nb, v["t_long"] / max(v["n_long"], 1), v["n_indep"] / nb))
+        print("  long matches per batch: %.1f copied one at a time (%.1f with source bytes before the window), %.0f cycles each; %.1f independent ones, four at a time; other long matches ready when one is copied: %.2f" %
+              (v["n_long"] / nb, v["n_long_g"] / nb, v["t_long"] / max(v["n_long"], 1), v["n_indep"] / nb, v["n_long_rdy"] / max(v["n_long"], 1)))
         print("  cycles/batch: count %.0f emit %.0f resolve %.0f flush %.0f window %.0f, all %.0f; header cycles/block %.0f" %
               (v["count_passes"] / nb, v["emit_pass"] / nb, v["resolve"] / nb, v["flush"] / nb, v["window"] / nb,
                v["total"] / nb, v["header"] / max(v["n_blocks"], 1)))
