@@ -1435,19 +1435,21 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveL
     if (swept) {
         u32 K = 0;
         for (u32 r0 = 0; r0 < M; r0 += 256) {
+            // (rounds beyond the list's end are skipped whole: literal-heavy batches have fewer than 64 tokens)
+            const bool h1 = r0 + 64 < M, h2 = r0 + 128 < M, h3 = r0 + 192 < M;     // wave-uniform
+            PreLoad p1, p2, p3;
+            p1.a = p1.b = 0; p1.tok = p1.dpos = p1.n_sh = p1.g = 0;
+            p2 = p1; p3 = p1;
             const PreLoad p0 = pre_load(raw, gwin, woff, tl, r0 + lane, M);
-            const PreLoad p1 = pre_load(raw, gwin, woff, tl, r0 + 64 + lane, M);
-            const PreLoad p2 = pre_load(raw, gwin, woff, tl, r0 + 128 + lane, M);
-            const PreLoad p3 = pre_load(raw, gwin, woff, tl, r0 + 192 + lane, M);
+            if (h1) p1 = pre_load(raw, gwin, woff, tl, r0 + 64 + lane, M);
+            if (h2) p2 = pre_load(raw, gwin, woff, tl, r0 + 128 + lane, M);
+            if (h3) p3 = pre_load(raw, gwin, woff, tl, r0 + 192 + lane, M);
             wave_sync();                                        // all four rounds' tokens are read before the list is compacted
             pre_store(outw, gwin, p0);
             K = pre_compact(tl, p0, r0 + lane < M, K, lane);
-            pre_store(outw, gwin, p1);
-            K = pre_compact(tl, p1, r0 + 64 + lane < M, K, lane);
-            pre_store(outw, gwin, p2);
-            K = pre_compact(tl, p2, r0 + 128 + lane < M, K, lane);
-            pre_store(outw, gwin, p3);
-            K = pre_compact(tl, p3, r0 + 192 + lane < M, K, lane);
+            if (h1) { pre_store(outw, gwin, p1); K = pre_compact(tl, p1, r0 + 64 + lane < M, K, lane); }
+            if (h2) { pre_store(outw, gwin, p2); K = pre_compact(tl, p2, r0 + 128 + lane < M, K, lane); }
+            if (h3) { pre_store(outw, gwin, p3); K = pre_compact(tl, p3, r0 + 192 + lane < M, K, lane); }
         }
         wave_sync();
         M = K;
