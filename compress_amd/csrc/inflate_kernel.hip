@@ -1008,8 +1008,9 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
         wp += (63 - cnt) >> 3;
         cnt |= 56;
         nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
-#pragma unroll
-        for (int step = 0; step < 2; step++) {
+        // two steps per top-up, one exit from the loop: a lane that finishes in the first step sits out the second
+        // (written with `goto out` in both steps, the compiler keeps a state variable to tell the exits apart)
+        auto one_step = [&]() -> bool {
             const u32 lo = (u32)buf;
             e = *(lds_cu32p)(uintptr_t)(tb + (__builtin_amdgcn_ubfe(lo, 0u, tw) << 2));
             const u32 take = e & 31, xb = __builtin_amdgcn_ubfe(e, 5u, 5u), val = e >> 16;
@@ -1040,10 +1041,12 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
             const u32 over = rem1 | ((u32)(OUT_CAP - 1) - nout);
             u32 stop = (over & m_tok) | e;
             if (EMIT) stop |= bad;
-            if ((i32)stop < 0) goto out;
-        }
+            return (i32)stop < 0;
+        };
+        bool fin = one_step();
+        if (!fin) fin = one_step();
+        if (fin) break;
     }
-out:
     u32 flag = F_NONE;
     if (e & E_STOP) flag = (e & E_EOB) ? F_EOB : F_CORRUPT;     // 286/287, 30/31, the degenerate filler
     else if (EMIT && bad) { nout -= len; nm--; flag = F_DIST; err_out = nout; }
