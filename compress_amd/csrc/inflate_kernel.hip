@@ -1097,8 +1097,8 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
         wp += (63 - cnt) >> 3;
         cnt |= 56;
         nextw = ((lds_cpu64p)(uintptr_t)wp)->v;
-#pragma unroll
-        for (int step = 0; step < 2; step++) {
+        // (two steps per top-up and one exit from the loop, as in decode_segment_fast)
+        auto one_step = [&]() -> bool {
             const u32 lo = (u32)buf;
             e = *(lds_cu32p)(uintptr_t)(tb + (__builtin_amdgcn_ubfe(lo, 0u, tw) << 2));
             if (CHECK) {
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
             tb = SEL(m_sub, val, SEL(m_len, tab1, tab0));
             tw = SEL(m_sub, xb, SEL(m_len, (u32)DIST_ROOT, (u32)LIT_ROOT));
             if (CHECK) {
-                if (hit) goto out;                              // nothing of this step counts
+                if (hit) return true;                           // nothing of this step counts
             }
             buf >>= take; cnt -= take; rel += take;
             if (!CHECK) {
@@ -1133,13 +1133,15 @@ __device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 
                 // seven zero bits read as the end of the block) and such a code counts as a token boundary for the exit
                 const u32 m_stop = (u32)__builtin_amdgcn_sbfe((int)e, 14u, 1u);
                 const u32 m_end = m_tok | (m_stop & ks_inv);
-                if ((i32)((over & m_end) | (e & ks_sign)) < 0) goto out;
+                return (i32)((over & m_end) | (e & ks_sign)) < 0;
             } else {
-                if ((i32)((over & m_tok) | e) < 0) goto out;
+                return (i32)((over & m_tok) | e) < 0;
             }
-        }
+        };
+        bool fin = one_step();
+        if (!fin) fin = one_step();
+        if (fin) break;
     }
-out:
 #undef MROW
     e_out = e;
     merged = CHECK && hit != 0;
