@@ -52,6 +52,7 @@ SYMBOLS = [
     "xfg_reader_set_window", "xfg_index_parse", "xfg_shard_plan", "xfg_flate_decode",
     "xfg_crc32_device", "xfg_crc32_combine", "xfg_decode_device_noalloc",
     "xfg_deflate_bound", "xfg_deflate", "xfg_deflate_device",
+    "xfg_set_decode_waves", "xfg_decode_waves_for",
 ]
 
 _lib = None
@@ -103,12 +104,19 @@ def lib():
     L.xfg_deflate_bound.restype = sz
     L.xfg_deflate.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
     L.xfg_deflate_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    L.xfg_set_decode_waves.argtypes = [ctypes.c_int]
+    L.xfg_decode_waves_for.argtypes = [ctypes.c_uint32, ctypes.c_int]
     _lib = L
     return L
 
 
 class TransportError(RuntimeError):
     pass
+
+
+def set_decode_waves(waves):
+    """xfg_set_decode_waves: 0 = by chunk count, 1 = one wavefront per chunk, 2..16 = a workgroup of that many."""
+    check(lib().xfg_set_decode_waves(waves), "xfg_set_decode_waves(%d)" % waves)
 
 
 def check(rc, what="xfg call"):

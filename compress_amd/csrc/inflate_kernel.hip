@@ -52,6 +52,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include "../../include/xflate_amd.h"
 #include "xfg_internal.h"
@@ -240,7 +241,9 @@ enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TO
        PF_N_BATCH, PF_N_PASS, PF_N_LIVE, PF_N_ROUNDS, PF_N_BLOCKS, PF_FLUSH, PF_N_TOKENS,
        PF_H_CLEN, PF_H_LENS, PF_H_LIT, PF_H_DIST, PF_R_SYNC, PF_R_SWEEP, PF_P_SPEC, PF_P_FIX, PF_P_COUNT, PF_N_FIX,
        PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB,
-       PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_N_LONG, PF_N_LONG_G, PF_T_LONG, PF_N_INDEP, PF_N_LONG_RDY, PF_COUNTERS = 40 };   // lanes a batch did not keep, by cause
+       PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_N_LONG, PF_N_LONG_G, PF_T_LONG, PF_N_INDEP, PF_N_LONG_RDY,
+       // the workgroup kernel: cycles spent waiting for the wave before (chain, count), the group's outcome, the water mark; events
+       PF_W_CHAIN, PF_W_CNT, PF_W_OUT, PF_W_WATER, PF_W_GROUPS, PF_W_ABORT, PF_W_ALONE, PF_W_REFIX, PF_COUNTERS = 48 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -284,7 +287,8 @@ constexpr u32 DUMP_POS = WT_BYTES + OUT_LDS + 16;
 static_assert(offsetof(WaveLds, out) == offsetof(WaveLds, win) + WT_BYTES && WT_BYTES % 16 == 0 && offsetof(WaveLds, win) % 16 == 0,
               "the output window follows the token list, 16-byte aligned");
 static_assert(DUMP_POS + 64 <= WT_BYTES + sizeof(((WaveLds *)nullptr)->out), "dump bytes lie inside the window's slack");
-__device__ __forceinline__ TokList token_list_n(WaveLds &L, u32 seg_bits, u32 max) {
+template <class LDS>
+__device__ __forceinline__ TokList token_list_n(LDS &L, u32 seg_bits, u32 max) {
     const u32 bwin = 8 * seg_bits + 64;
     TokList t;
     t.max = max;
@@ -292,7 +296,8 @@ __device__ __forceinline__ TokList token_list_n(WaveLds &L, u32 seg_bits, u32 ma
     t.tdst = reinterpret_cast<u16 *>(t.tok + t.max);
     return t;
 }
-__device__ __forceinline__ TokList token_list(WaveLds &L, u32 seg_bits) {
+template <class LDS>
+__device__ __forceinline__ TokList token_list(LDS &L, u32 seg_bits) {
     const u32 bwin = 8 * seg_bits + 64;
     TokList t;
     t.max = ((u32)WT_BYTES - bwin) / 6;
@@ -453,8 +458,8 @@ __device__ __forceinline__ u32 reader_bitpos(const Reader &r) { return r.bytepos
 // Returns 0 = ok, 1 = empty code (decode with it is an error), 2 = invalid
 // (over/under-subscribed: GeneratePrefixes errors, prefix.go:355-369).
 // ---------------------------------------------------------------------------
-template <int TYPE, int ROOT, int TAB_OFF>
-__device__ int build_table(WaveLds &L, u32 *tab, const u8 *lens, u32 n, u32 lane) {
+template <int TYPE, int ROOT, int TAB_OFF, class LDS>
+__device__ int build_table(LDS &L, u32 *tab, const u8 *lens, u32 n, u32 lane) {
     // 1. histogram of code lengths
 #ifdef XFG_PROFILE
     const unsigned long long bt0_ = __builtin_amdgcn_s_memtime();
@@ -607,8 +612,11 @@ struct Out {
 };
 
 // readRawData (flate/reader.go:137-159): n bytes from stream position sp to the output,
-// 16 bytes per lane and step with the stores aligned (the loads may straddle).
-__device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32 n, u32 lane) {
+// 16 bytes per lane and step with the stores aligned (the loads may straddle).  lane counts over
+// the NL lanes that copy together: one wave's 64, or all the waves of a workgroup (inflate_wg_kernel.inc).
+template <u32 NLC = 64>
+__device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32 n, u32 lane, u32 nl_rt = 64) {
+    const u32 NL = NLC ? NLC : nl_rt;                           // compile-time for the one-wave kernel
     const u8 *src = r.comp + r.base_al + r.lead + sp;
     u8 *dst = o.raw + o.pos;
     u32 fast = 0;                                               // bytes inside the chunk proper
@@ -619,40 +627,40 @@ __device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32
     const u32 body = (fast - head) >> 4;
     u32 i = lane;
 #if XFG_STORED_DEEP
-    for (; i + 448 < body; i += 512) {                          // eight loads in flight per lane
+    for (; i + 7 * NL < body; i += 8 * NL) {                    // eight loads in flight per lane
         uint4 v0, v1, v2, v3, v4, v5, v6, v7;
-        __builtin_memcpy(&v0, src + head + (size_t)(i + 0) * 16, 16);
-        __builtin_memcpy(&v1, src + head + (size_t)(i + 64) * 16, 16);
-        __builtin_memcpy(&v2, src + head + (size_t)(i + 128) * 16, 16);
-        __builtin_memcpy(&v3, src + head + (size_t)(i + 192) * 16, 16);
-        __builtin_memcpy(&v4, src + head + (size_t)(i + 256) * 16, 16);
-        __builtin_memcpy(&v5, src + head + (size_t)(i + 320) * 16, 16);
-        __builtin_memcpy(&v6, src + head + (size_t)(i + 384) * 16, 16);
-        __builtin_memcpy(&v7, src + head + (size_t)(i + 448) * 16, 16);
+        __builtin_memcpy(&v0, src + head + (size_t)(i + 0 * NL) * 16, 16);
+        __builtin_memcpy(&v1, src + head + (size_t)(i + 1 * NL) * 16, 16);
+        __builtin_memcpy(&v2, src + head + (size_t)(i + 2 * NL) * 16, 16);
+        __builtin_memcpy(&v3, src + head + (size_t)(i + 3 * NL) * 16, 16);
+        __builtin_memcpy(&v4, src + head + (size_t)(i + 4 * NL) * 16, 16);
+        __builtin_memcpy(&v5, src + head + (size_t)(i + 5 * NL) * 16, 16);
+        __builtin_memcpy(&v6, src + head + (size_t)(i + 6 * NL) * 16, 16);
+        __builtin_memcpy(&v7, src + head + (size_t)(i + 7 * NL) * 16, 16);
         asm volatile("" ::: "memory");                          // all loads are issued before the first store
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 0) * 16) = v0;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 64) * 16) = v1;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 128) * 16) = v2;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 192) * 16) = v3;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 256) * 16) = v4;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 320) * 16) = v5;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 384) * 16) = v6;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 448) * 16) = v7;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 0 * NL) * 16) = v0;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 1 * NL) * 16) = v1;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 2 * NL) * 16) = v2;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 3 * NL) * 16) = v3;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 4 * NL) * 16) = v4;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 5 * NL) * 16) = v5;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 6 * NL) * 16) = v6;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 7 * NL) * 16) = v7;
     }
 #endif
-    for (; i + 192 < body; i += 256) {                          // four
+    for (; i + 3 * NL < body; i += 4 * NL) {                    // four
         uint4 v0, v1, v2, v3;
-        __builtin_memcpy(&v0, src + head + (size_t)(i + 0) * 16, 16);
-        __builtin_memcpy(&v1, src + head + (size_t)(i + 64) * 16, 16);
-        __builtin_memcpy(&v2, src + head + (size_t)(i + 128) * 16, 16);
-        __builtin_memcpy(&v3, src + head + (size_t)(i + 192) * 16, 16);
+        __builtin_memcpy(&v0, src + head + (size_t)(i + 0 * NL) * 16, 16);
+        __builtin_memcpy(&v1, src + head + (size_t)(i + 1 * NL) * 16, 16);
+        __builtin_memcpy(&v2, src + head + (size_t)(i + 2 * NL) * 16, 16);
+        __builtin_memcpy(&v3, src + head + (size_t)(i + 3 * NL) * 16, 16);
         asm volatile("" ::: "memory");                          // all loads are issued before the first store
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 0) * 16) = v0;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 64) * 16) = v1;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 128) * 16) = v2;
-        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 192) * 16) = v3;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 0 * NL) * 16) = v0;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 1 * NL) * 16) = v1;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 2 * NL) * 16) = v2;
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)(i + 3 * NL) * 16) = v3;
     }
-    for (; i < body; i += 64) {
+    for (; i < body; i += NL) {
         uint4 v;
         __builtin_memcpy(&v, src + head + (size_t)i * 16, 16);
         *reinterpret_cast<uint4 *>(dst + head + (size_t)i * 16) = v;
@@ -660,7 +668,7 @@ __device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32
     const u32 done = head + body * 16;
     if (done + lane < fast) dst[done + lane] = src[done + lane];
     // a stored block that claims more than the chunk holds runs into the appended endBlock
-    for (u32 k = fast + lane; k < n; k += 64) {
+    for (u32 k = fast + lane; k < n; k += NL) {
         const u32 t = sp + k - r.csize;
         dst[k] = (t == 0) ? 0x01 : (t >= 3 ? 0xff : 0x00);
     }
@@ -670,7 +678,8 @@ __device__ __forceinline__ void stored_copy(const Reader &r, Out &o, u32 sp, u32
 __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 &total);
 
 // ReadPrefixCodes (flate/prefix.go:83-194).  Returns an XFG_ST_* status.
-__device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep16, int &lit_state, int &dist_state) {
+template <class LDS>
+__device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, int &lit_state, int &dist_state) {
     refill(r);
     // three ReadBits; each one either gets all its bits or fails consuming none
     if (avail(r) < 5) return XFG_ST_UNEXPECTED_EOF;
@@ -822,7 +831,8 @@ __device__ int read_dynamic_header(Reader &r, WaveLds &L, u32 lane, bool rfc_rep
 }
 
 // Fixed code sets of RFC 1951 3.2.6 (flate/prefix.go:35-63).
-__device__ void build_fixed(WaveLds &L, u32 lane) {
+template <class LDS>
+__device__ void build_fixed(LDS &L, u32 lane) {
     for (u32 i = lane; i < 288; i += 64)
         L.h.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
     wave_sync();
@@ -885,7 +895,8 @@ __device__ __forceinline__ void fetch_batch_window(const Reader &r, i32 wb0, u32
         pf[u] = v;
     }
 }
-__device__ __forceinline__ void store_batch_window(WaveLds &L, u32 lane, const uint4 (&pf)[NPF]) {
+template <class LDS>
+__device__ __forceinline__ void store_batch_window(LDS &L, u32 lane, const uint4 (&pf)[NPF]) {
     u8 *dst = reinterpret_cast<u8 *>(L.win);
 #pragma unroll
     for (int u = 0; u < NPF; u++) {
@@ -905,8 +916,8 @@ __device__ __forceinline__ void store_batch_window(WaveLds &L, u32 lane, const u
 //   (obase = the same position counted from the start of the chunk), matches to tok/tdst at moff..
 //   TAIL = true: the batch may run past the end of the stream; every read of the reference
 //   that can fail with io.ErrUnexpectedEOF is checked at the same point.
-template <bool EMIT>
-__device__ __forceinline__ Seg decode_segment_tail(WaveLds &L, const TokList tl, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
+template <bool EMIT, class LDS>
+__device__ __forceinline__ Seg decode_segment_tail(LDS &L, const TokList tl, i32 wb0, u32 start, u32 seg_end, u32 total_bits,
                                                    bool dist_empty, u32 orel, u32 obase, u32 moff, u32 &err_out)
 {
     const u32 *win = reinterpret_cast<const u32 *>(L.win);
@@ -982,8 +993,11 @@ typedef const __attribute__((address_space(3))) u8 *lds_cu8p;
 struct __attribute__((packed)) PackedU64 { u64 v; };             // 8 bytes at any alignment
 typedef const __attribute__((address_space(3))) PackedU64 *lds_cpu64p;
 
-template <bool EMIT>
-__device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl, i32 wb0, u32 start, u32 seg_end,
+// (NEED, with EMIT = false: err_out becomes the history the lane's matches need before the lane's first byte,
+// max over its matches of distance - bytes the lane has produced by then, as an i32: the count pass of the
+// workgroup kernel finds a distance beyond the history, flate/reader.go:223-225, before anything is written.)
+template <bool EMIT, bool NEED = false, class LDS>
+__device__ __forceinline__ Seg decode_segment_fast(LDS &L, const TokList tl, i32 wb0, u32 start, u32 seg_end,
                                                    u32 orel, u32 obase, u32 moff, u32 lane, u32 &err_out)
 {
     // LDS byte addresses: the lookup state is the address of the table the next step indexes
@@ -1002,6 +1016,7 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
     u32 nout = 0, nm = 0, len = 0;
     u32 tb = tab0, tw = LIT_ROOT;
     u32 e = 0, bad = 0;
+    i32 need = (i32)0x80000000;
     for (;;) {
         // top up; the 8 bytes after it are already on their way for the next top-up
         buf |= nextw << cnt;
@@ -1031,6 +1046,10 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
                     tl.tdst[moff + nm] = (u16)(orel + nout);
                 }
             }
+            if (NEED) {
+                const i32 cand = (i32)SEL(m_dist, value - nout, 0x80000000u);
+                need = cand > need ? cand : need;
+            }
             tb = SEL(m_sub, val, SEL(m_len, tab1, tab0));
             tw = SEL(m_sub, xb, SEL(m_len, (u32)DIST_ROOT, (u32)LIT_ROOT));
             len = SEL(m_len, value, len);
@@ -1050,6 +1069,7 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
     u32 flag = F_NONE;
     if (e & E_STOP) flag = (e & E_EOB) ? F_EOB : F_CORRUPT;     // 286/287, 30/31, the degenerate filler
     else if (EMIT && bad) { nout -= len; nm--; flag = F_DIST; err_out = nout; }
+    if (NEED) err_out = (u32)need;
     Seg r;
     r.end = seg_end - 1 - rem1; r.nout = nout; r.nmatch = nm; r.flag = flag;
     return r;
@@ -1063,8 +1083,8 @@ __device__ __forceinline__ Seg decode_segment_fast(WaveLds &L, const TokList tl,
 //                  marked position: from that point on it would repeat the speculative path, so
 //                  that path's end is its end (returns merged = true), or until its own end.
 // Returns the bit position after the last token; e_out = the entry that ended the walk.
-template <bool CHECK, bool RUNIN>
-__device__ __forceinline__ u32 sync_segment(WaveLds &L, i32 wb0, u32 start, u32 seg_start, u32 seg_bits, u32 lane,
+template <bool CHECK, bool RUNIN, class LDS>
+__device__ __forceinline__ u32 sync_segment(LDS &L, i32 wb0, u32 start, u32 seg_start, u32 seg_bits, u32 lane,
                                             u32 &e_out, bool &merged, u32 keep_stop = ~0u)
 {
     const u32 tab0 = (u32)(uintptr_t)(lds_cu32p)L.tab;
@@ -1431,7 +1451,8 @@ __device__ __forceinline__ u32 pre_compact(const TokList tl, const PreLoad &p, b
 // beyond its foreign source bytes it has written itself.  Matches of LONG_MATCH bytes and more
 // are not copied by their lane: when such a token is the first unresolved one, the whole wave
 // copies it (copy_long_match).
-__device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, WaveLds &L, const TokList tl, u32 M, u32 lane) {
+template <class LDS>
+__device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, LDS &L, const TokList tl, u32 M, u32 lane) {
     u8 *outw = reinterpret_cast<u8 *>(L.win);               // positions count from the start of L.win
     const u8 *gwin = raw + base - woff;                         // HBM address of window position 0
     u32 rounds = 0;
@@ -1603,8 +1624,14 @@ __device__ __forceinline__ u32 seg_bits_for(u32 out_bytes, u32 in_bits) {
 #endif
 }
 
-__device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u32 lane, u32 p0,
-                                         int lit_state, int dist_state, u32 spec_back, u32 max_fix, u32 &seg_bits)
+// (WG = true: called by wave 0 of the workgroup-per-chunk kernel for the stretches its waves do not share -- batches
+// near the end of the stream, blocks without a distance code, serial batches, anything that ended a group with an
+// error: decodes at least one batch and returns XFG_ST_AGAIN at the first batch that is an ordinary parallel one.)
+constexpr int XFG_ST_AGAIN = -100;                              // never leaves the kernel
+template <bool WG = false, class LDS>
+__device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 lane, u32 p0,
+                                         int lit_state, int dist_state, u32 spec_back, u32 max_fix, u32 &seg_bits,
+                                         bool serial_init = false)
 {
     BlockEnd be;
     if (lit_state == 1) { be.status = XFG_ST_CORRUPTED; be.bitpos = p0; return be; }   // empty literal tree
@@ -1614,9 +1641,10 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, WaveLds &L, u3
     uint4 pf[NPF];
     bool have_pf = false, force_tail = false;
     u32 want = 64;                                              // lanes worth synchronising: what the last batch could keep, and some
-    bool serial = false;                                        // output-bound stretch (long matches): lane 0 decodes alone
+    bool serial = WG && serial_init;                            // output-bound stretch (long matches): lane 0 decodes alone
     for (u32 nbatch = 0;; nbatch++) {
         if (nbatch > total_bits + 4) { be.status = XFG_ST_INTERNAL; be.bitpos = p0; return be; }   // every batch consumes >= 1 bit
+        if (WG && nbatch > 0 && !dist_empty && !force_tail && !serial && p0 + 64u <= total_bits) { be.status = XFG_ST_AGAIN; be.bitpos = p0; return be; }
         // ---- compressed window of this batch (fetched during the previous batch's stage 2 when there was one)
         const i32 wb0 = (i32)(((stream0 + (p0 >> 3)) & ~(i64)15) - stream0);
         {
@@ -2142,6 +2170,8 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, u64 comp_len, const xfg_chunk
     }
 }
 
+#include "inflate_wg_kernel.inc"
+
 } // namespace xfg
 
 #ifdef XFG_PROFILE
@@ -2258,14 +2288,74 @@ extern "C" int xfg_decode_device_noalloc(int device, const void *d_comp, size_t 
     return rc;
 }
 
+// ---------------------------------------------------------------------------
+// One wave per chunk, or a workgroup per chunk (inflate_wg_kernel.inc)?  A table with fewer chunks than half the
+// chip's wave slots is decoded by workgroups of slots / n waves (at most 16): the same bytes, statuses and offsets,
+// sooner.  xfg_set_decode_waves() / XFG_DECODE_WAVES pin the choice (tests, measurements).
+// ---------------------------------------------------------------------------
+namespace {
+std::atomic<int> g_decode_waves{-1};                            // -1: not set yet (the environment decides), 0: by chunk count
+int decode_waves_setting()
+{
+    int w = g_decode_waves.load(std::memory_order_relaxed);
+    if (w < 0) {
+        const char *e = getenv("XFG_DECODE_WAVES");
+        w = e && *e ? atoi(e) : 0;
+        if (w < 0 || w > xfg::WG_MAX_WAVES) w = 0;
+        g_decode_waves.store(w, std::memory_order_relaxed);
+    }
+    return w;
+}
+// workgroups of `waves` waves that one CU holds (LDS- and register-bound), per wave count; 0 = not asked yet
+std::atomic<int> g_wg_per_cu[xfg::WG_MAX_WAVES + 1];
+int wg_blocks_per_cu(int waves)
+{
+    int nb = g_wg_per_cu[waves].load(std::memory_order_relaxed);
+    if (nb > 0) return nb;
+    const size_t lds = xfg::wg_lds_bytes((uint32_t)waves);
+    // more than 64 KB of dynamic LDS has to be asked for
+    (void)hipFuncSetAttribute((const void *)xfg::inflate_chunks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xfg::wg_lds_bytes(xfg::WG_MAX_WAVES));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg_kernel, 64 * waves, lds) != hipSuccess || nb < 1) nb = 1;
+    g_wg_per_cu[waves].store(nb, std::memory_order_relaxed);
+    return nb;
+}
+}
+
+extern "C" int xfg_set_decode_waves(int waves)
+{
+    if (waves < 0 || waves > xfg::WG_MAX_WAVES) return XFG_E_ARG;
+    g_decode_waves.store(waves, std::memory_order_relaxed);
+    return XFG_OK;
+}
+
+// waves per chunk for a table of n chunks (1 = inflate_chunks_kernel)
+extern "C" int xfg_decode_waves_for(uint32_t n, int num_cu)
+{
+    const int forced = decode_waves_setting();
+    if (forced) return forced;
+    const uint64_t slots = (uint64_t)num_cu * (uint64_t)blocks_per_cu();     // waves the chip holds
+    uint64_t w = n ? slots / n : 1;
+    if (w > (uint64_t)xfg::WG_MAX_WAVES) w = xfg::WG_MAX_WAVES;
+    return w < 2 ? 1 : (int)w;
+}
+
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, const void *d_chunks, uint32_t n,
                                          void *d_raw, size_t raw_len, void *d_res, void *d_scratch,
                                          int num_cu, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    const uint32_t blocks = xfg_grid_blocks(n, num_cu);
     hipError_t e = hipMemsetAsync(d_scratch, 0, 64 * xfg::DRAW_SLICES, stream);      // the chunk counters
     if (e != hipSuccess) return e;
+    const int waves = xfg_decode_waves_for(n, num_cu);
+    if (waves >= 2) {
+        uint32_t blocks = (uint32_t)num_cu * (uint32_t)wg_blocks_per_cu(waves);
+        if (blocks > n) blocks = n;
+        hipLaunchKernelGGL(xfg::inflate_chunks_wg_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves), stream,
+                           (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
+                           (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch);
+        return hipGetLastError();
+    }
+    const uint32_t blocks = xfg_grid_blocks(n, num_cu);
     hipLaunchKernelGGL(xfg::inflate_chunks_kernel, dim3(blocks), dim3(64 * xfg::WAVES_PER_BLOCK), 0, stream,
                        (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
                        (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch);

@@ -161,6 +161,18 @@ int xfg_decode_device_noalloc(int device, const void *d_comp, size_t comp_len,
                               const void *d_chunks, size_t n,
                               void *d_raw, size_t raw_len, void *d_res, void *hip_stream);
 /*
+ * How many wavefronts decode one chunk.  No counterpart in the reference (whose Reader decodes one chunk at a
+ * time on one goroutine, xflate/reader.go:162-215); a tuning and test knob.  0 (the default, or what the
+ * environment variable XFG_DECODE_WAVES says): chosen per launch from the chunk count -- a table with at least
+ * half as many chunks as the GPU has wave slots (4096 on MI355X) gives every chunk one wavefront, a smaller one
+ * gives every chunk a workgroup of up to 16 wavefronts that decode consecutive batches of the chunk's blocks
+ * together (a Reader's window, flate.NewReader's single stream, a few huge chunks).  1: always one wavefront.
+ * 2..16: always a workgroup of that many.  Results are bit-identical whatever the setting.  Process-wide; returns
+ * XFG_E_ARG for any other value.  xfg_decode_waves_for() says what a launch of n chunks would use.
+ */
+int xfg_set_decode_waves(int waves);
+int xfg_decode_waves_for(uint32_t n, int num_cu);
+/*
  * CRC-32 (IEEE 802.3: Go's hash/crc32.IEEE, the checksum of gzip trailers and of the XFLATE
  * index, xflate/reader.go:386) of every chunk's decoded bytes, computed where they are: the
  * reference's gzip embedding hashes on the CPU while writing (xflate/example_test.go:171-182),
