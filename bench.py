@@ -58,6 +58,14 @@ WORKLOADS = {
     "c3_stream": (131072, 262144, ("huffman", "repeats", "digits"), 6, 384),
     "c3_stream_small": (8192, 262144, ("huffman", "repeats", "digits"), 6, 96),   # the same path at 2 GiB (rehearsals, tests)
     "c2x4": (65536, 65536, ("huffman", "repeats", "digits"), 6, 768),    # diagnostic: how much of c2's time is the grid's tail
+    # diagnostics for the workgroup-per-chunk mode: few chunks, one data shape each
+    "small_huffman": (768, 65536, ("huffman",), 6, 96),
+    "small_repeats": (768, 65536, ("repeats",), 6, 96),
+    "small_digits": (768, 65536, ("digits",), 6, 96),
+    "small_text": (768, 65536, ("text",), 6, 64),
+    "one_text_64k": (1, 65536, ("text",), 6, 1),
+    "one_text_4m": (1, 4 << 20, ("text",), 6, 1),
+    "few_text_256k": (64, 262144, ("text",), 6, 16),
 
     # single-kind diagnostics (not bench lines): where does the time go per data shape
     "huffman": (16384, 65536, ("huffman",), 6, 256),

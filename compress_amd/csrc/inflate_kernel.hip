@@ -243,7 +243,8 @@ enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TO
        PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB,
        PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_N_LONG, PF_N_LONG_G, PF_T_LONG, PF_N_INDEP, PF_N_LONG_RDY,
        // the workgroup kernel: cycles spent waiting for the wave before (chain, count), the group's outcome, the water mark; events
-       PF_W_CHAIN, PF_W_CNT, PF_W_OUT, PF_W_WATER, PF_W_GROUPS, PF_W_ABORT, PF_W_ALONE, PF_W_REFIX, PF_COUNTERS = 48 };   // lanes a batch did not keep, by cause
+       PF_W_CHAIN, PF_W_CNT, PF_W_OUT, PF_W_WATER, PF_W_GROUPS, PF_W_ABORT, PF_W_ALONE, PF_W_REFIX,
+       PF_D0, PF_D1, PF_D2, PF_D3, PF_D4, PF_D5, PF_D6, PF_D7, PF_COUNTERS = 56 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -270,6 +271,10 @@ struct alignas(16) WaveLds {
 #ifdef XFG_PROFILE
     unsigned long long prof[PF_COUNTERS];
 #endif
+    // bytes from the start of win that a round's token list and output window share, and where the bytes go that
+    // nobody reads (DUMP_POS below); the workgroup kernel's waves may have more room (inflate_wg_kernel.inc)
+    static constexpr u32 room_total = WT_BYTES + OUT_LDS;
+    static constexpr u32 dump = WT_BYTES + OUT_LDS + 16;
 };
 static_assert(sizeof(HeaderScratch) <= OUT_LDS, "header scratch must fit the output window");
 
@@ -286,7 +291,7 @@ constexpr u32 OUT_POS = WT_BYTES;
 constexpr u32 DUMP_POS = WT_BYTES + OUT_LDS + 16;
 static_assert(offsetof(WaveLds, out) == offsetof(WaveLds, win) + WT_BYTES && WT_BYTES % 16 == 0 && offsetof(WaveLds, win) % 16 == 0,
               "the output window follows the token list, 16-byte aligned");
-static_assert(DUMP_POS + 64 <= WT_BYTES + sizeof(((WaveLds *)nullptr)->out), "dump bytes lie inside the window's slack");
+static_assert(DUMP_POS + 64 <= WT_BYTES + sizeof(((WaveLds *)nullptr)->out) && DUMP_POS == WaveLds::dump, "dump bytes lie inside the window's slack");
 template <class LDS>
 __device__ __forceinline__ TokList token_list_n(LDS &L, u32 seg_bits, u32 max) {
     const u32 bwin = 8 * seg_bits + 64;
@@ -1017,6 +1022,7 @@ __device__ __forceinline__ Seg decode_segment_fast(LDS &L, const TokList tl, i32
     u32 tb = tab0, tw = LIT_ROOT;
     u32 e = 0, bad = 0;
     i32 need = (i32)0x80000000;
+    const u32 dump_at = L.dump + lane;
     for (;;) {
         // top up; the 8 bytes after it are already on their way for the next top-up
         buf |= nextw << cnt;
@@ -1037,7 +1043,7 @@ __device__ __forceinline__ Seg decode_segment_fast(LDS &L, const TokList tl, i32
             const u32 m_tok = (u32)__builtin_amdgcn_sbfe((int)e, 15u, 1u);
             if (EMIT) {
                 // a literal goes to its place; every other step writes a byte nobody reads
-                outw[SEL(m_lit, orel + nout, (u32)DUMP_POS + lane)] = (u8)val;
+                outw[SEL(m_lit, orel + nout, dump_at)] = (u8)val;
                 if (m_dist) {
                     const u32 dst = obase + nout;
                     const u32 hist = dst < (u32)MAX_HIST ? dst : (u32)MAX_HIST;  // dictDecoder.HistSize
@@ -1822,7 +1828,7 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
             // matches moves the border up, a round of long ones down (six bytes per token, and the list's length is
             // rounded up to eight tokens so that the window stays 16-byte aligned).  One lane always fits:
             // <= SEG_MAX / 2 tokens and < OUT_LDS bytes.  (A batch that lane 0 has emitted already used the fixed border.)
-            const u32 room = (u32)(WT_BYTES + OUT_LDS) - (8 * seg_bits + 64);
+            const u32 room = L.room_total - (8 * seg_bits + 64);
             const bool keep = live && lane >= b0 &&
                               (emitted ? rel + sg.nout <= (u32)OUT_LDS && moff + sg.nmatch <= tl.max
                                        : 6 * (moff + sg.nmatch + 7) + rel + sg.nout <= room);
@@ -2312,9 +2318,9 @@ int wg_blocks_per_cu(int waves)
 {
     int nb = g_wg_per_cu[waves].load(std::memory_order_relaxed);
     if (nb > 0) return nb;
-    const size_t lds = xfg::wg_lds_bytes((uint32_t)waves);
+    const size_t lds = xfg::wg_lds_bytes((uint32_t)waves, xfg::wg_extra_bytes((uint32_t)waves));
     // more than 64 KB of dynamic LDS has to be asked for
-    (void)hipFuncSetAttribute((const void *)xfg::inflate_chunks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xfg::wg_lds_bytes(xfg::WG_MAX_WAVES));
+    (void)hipFuncSetAttribute((const void *)xfg::inflate_chunks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xfg::WG_LDS_MAX);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg_kernel, 64 * waves, lds) != hipSuccess || nb < 1) nb = 1;
     g_wg_per_cu[waves].store(nb, std::memory_order_relaxed);
     return nb;
@@ -2350,9 +2356,10 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, co
     if (waves >= 2) {
         uint32_t blocks = (uint32_t)num_cu * (uint32_t)wg_blocks_per_cu(waves);
         if (blocks > n) blocks = n;
-        hipLaunchKernelGGL(xfg::inflate_chunks_wg_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves), stream,
+        const uint32_t extra = xfg::wg_extra_bytes((uint32_t)waves);
+        hipLaunchKernelGGL(xfg::inflate_chunks_wg_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves, extra), stream,
                            (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
-                           (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch);
+                           (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch, extra);
         return hipGetLastError();
     }
     const uint32_t blocks = xfg_grid_blocks(n, num_cu);

@@ -17,7 +17,9 @@ NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "
          "n_batch", "n_pass", "n_live_lanes", "n_rounds", "n_blocks", "flush", "n_tokens",
          "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix",
          "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "t_sort", "t_root", "t_sub",
-         "n_wfull", "n_wf_tok", "n_wf_out", "n_long", "n_long_g", "t_long", "n_indep", "n_long_rdy"]
+         "n_wfull", "n_wf_tok", "n_wf_out", "n_long", "n_long_g", "t_long", "n_indep", "n_long_rdy",
+         "w_chain", "w_cnt", "w_out", "w_water", "w_groups", "w_abort", "w_alone", "w_refix",
+         "d0", "d1", "d2", "d3", "d4", "d5", "d6", "d7"]
 
 
 def main():
@@ -31,13 +33,13 @@ def main():
         d_raw = torch.zeros(shard["raw_len"] + 64, dtype=torch.uint8, device=dev)
         d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
         L = capi.lib()
-        buf = (ctypes.c_ulonglong * 40)()
+        buf = (ctypes.c_ulonglong * 56)()
         for it in range(2):
-            L.xfg_debug_profile(buf, 40)          # clear
+            L.xfg_debug_profile(buf, 56)          # clear
             ctx.decode_device(d_comp.data_ptr(), len(shard["comp"]), d_chunks.data_ptr(), n,
                               d_raw.data_ptr(), shard["raw_len"], d_res.data_ptr(), None)
             ctx.sync()
-        L.xfg_debug_profile(buf, 40)
+        L.xfg_debug_profile(buf, 56)
         v = {k: buf[i] for i, k in enumerate(NAMES)}
         tot = max(v["total"], 1)
         print("== %s: %d chunks" % (w, n))
@@ -63,6 +65,13 @@ def main():
         print("  cycles/batch: count %.0f emit %.0f resolve %.0f flush %.0f window %.0f, all %.0f; header cycles/block %.0f" %
               (v["count_passes"] / nb, v["emit_pass"] / nb, v["resolve"] / nb, v["flush"] / nb, v["window"] / nb,
                v["total"] / nb, v["header"] / max(v["n_blocks"], 1)))
+        if v["w_groups"]:
+            ng = v["w_groups"]          # counted by every wave of the workgroup
+            print("  workgroup mode (waves per chunk: %d): wave-cycles waiting for the wave before: chain %.0f, count %.0f; for the group's outcome %.0f; "
+                  "for the water mark %.0f per batch; group calls %d, aborted %d, stretches wave 0 decoded alone %d, chains repaired after the wave before settled %d" %
+                  (L.xfg_decode_waves_for(n, 256), v["w_chain"] / nb, v["w_cnt"] / nb, v["w_out"] / nb, v["w_water"] / nb, ng, v["w_abort"], v["w_alone"], v["w_refix"]))
+        if v["d0"]:
+            print("  debug:", " ".join("%s=%.2f" % (k, v[k] / v["d0"]) for k in ("d1", "d2", "d3", "d4", "d5", "d6", "d7")), "per d0 =", v["d0"])
         ctx.close()
 
 
