@@ -243,8 +243,7 @@ enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TO
        PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB,
        PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_N_LONG, PF_N_LONG_G, PF_T_LONG, PF_N_INDEP, PF_N_LONG_RDY,
        // the workgroup kernel: cycles spent waiting for the wave before (chain, count), the group's outcome, the water mark; events
-       PF_W_CHAIN, PF_W_CNT, PF_W_OUT, PF_W_WATER, PF_W_GROUPS, PF_W_ABORT, PF_W_ALONE, PF_W_REFIX,
-       PF_D0, PF_D1, PF_D2, PF_D3, PF_D4, PF_D5, PF_D6, PF_D7, PF_COUNTERS = 56 };   // lanes a batch did not keep, by cause
+       PF_W_CHAIN, PF_W_CNT, PF_W_OUT, PF_W_WATER, PF_W_GROUPS, PF_W_ABORT, PF_W_ALONE, PF_W_REFIX, PF_COUNTERS = 48 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -336,6 +335,26 @@ __device__ __forceinline__ u64 uni64(u64 v) {
     u32 lo = __builtin_amdgcn_readfirstlane((u32)v);
     u32 hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
     return ((u64)hi << 32) | lo;
+}
+
+// A pointer that is known to point into LDS, said so that the compiler can tell: through the address space and back.
+// Where a function is not inlined (or its LDS comes through references, as in the workgroup kernel's WgLds) the
+// compiler otherwise falls back to flat instructions for every access.
+template <class T>
+__device__ __forceinline__ T *in_lds(T *p) {
+    typedef __attribute__((address_space(3))) T *lds_p;
+    u32 a = (u32)(uintptr_t)(lds_p)p;
+    asm("" : "+v"(a));                                          // (opaque, so that the round trip is not folded away)
+    return (T *)(lds_p)(uintptr_t)a;
+}
+
+// The same for a pointer into global memory.
+template <class T>
+__device__ __forceinline__ T *in_global(T *p) {
+    typedef __attribute__((address_space(1))) T *glb_p;
+    u64 a = (u64)(uintptr_t)(glb_p)p;
+    asm("" : "+v"(a));
+    return (T *)(glb_p)(uintptr_t)a;
 }
 
 // ---------------------------------------------------------------------------
@@ -464,7 +483,19 @@ __device__ __forceinline__ u32 reader_bitpos(const Reader &r) { return r.bytepos
 // (over/under-subscribed: GeneratePrefixes errors, prefix.go:355-369).
 // ---------------------------------------------------------------------------
 template <int TYPE, int ROOT, int TAB_OFF, class LDS>
-__device__ int build_table(LDS &L, u32 *tab, const u8 *lens, u32 n, u32 lane) {
+__device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane) {
+    struct View { HeaderScratch &h; u32 *tab;
+#ifdef XFG_PROFILE
+                  unsigned long long *prof;
+#endif
+    };
+    View L{*in_lds(&L_.h), in_lds(&L_.tab[0])
+#ifdef XFG_PROFILE
+           , in_lds(&L_.prof[0])
+#endif
+    };
+    u32 *tab = in_lds(tab_);
+    const u8 *lens = in_lds(lens_);
     // 1. histogram of code lengths
 #ifdef XFG_PROFILE
     const unsigned long long bt0_ = __builtin_amdgcn_s_memtime();
@@ -1249,11 +1280,40 @@ __device__ __forceinline__ void copy16_g2l(u8 *dst, const u8 *src, u32 n) {
     }
 }
 
+// Where the bytes of a match source that lie BEFORE the window come from.  Window position p (< woff) is the chunk's
+// output byte base - woff + p.  at(p) points at that byte and at least 48 more bytes that may be read (not
+// necessarily meaningful ones); lo() is the window position of the chunk's first byte, below which nothing exists.
+//   SrcHbm   the chunk's output in HBM, through L2: everything before the window has been flushed (the one-wave kernel)
+//   SrcRing  the workgroup kernel's history ring in LDS (inflate_wg_kernel.inc): the last 32 KB of output before
+//            the window, byte q of the chunk at ring offset (q + the output's HBM address mod 16) mod 32 KB,
+//            with the ring's first 64 bytes repeated behind its end
+constexpr u32 RING_BYTES = 32768, RING_MIRROR = 64;
+struct SrcHbm {
+    const u8 *gwin;     // HBM address of window position 0
+    i32 pmin;
+    static constexpr bool always_readable = false;              // the chunk may be shorter than the 8 bytes an idle lane reads
+    __device__ __forceinline__ const u8 *at(i32 p) const { return gwin + p; }
+    __device__ __forceinline__ i32 lo() const { return pmin; }
+    __device__ __forceinline__ SrcHbm known() const { SrcHbm k; k.gwin = in_global(gwin); k.pmin = pmin; return k; }
+};
+struct SrcRing {
+    u32 ring;           // LDS byte address of the ring
+    u32 gbase;          // ring key of window position 0
+    i32 pmin;
+    static constexpr bool always_readable = true;
+    __device__ __forceinline__ const u8 *at(i32 p) const {
+        return (const u8 *)(lds_cu8p)(uintptr_t)(ring + ((gbase + (u32)p) & (RING_BYTES - 1)));
+    }
+    __device__ __forceinline__ i32 lo() const { return pmin; }
+    __device__ __forceinline__ SrcRing known() const { return *this; }
+};
+
 // One long match, copied by the whole wave: byte j of the match is source byte j mod dist
 // (flate/dict_decoder.go:93-100 in closed form).  The dist source bytes end where the destination
 // starts and are final (window) or lie before the window (HBM/L2), so all reads precede all writes
 // of the same bytes and the 64 lanes need no ordering among themselves.
-__device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 woff, u32 d, u32 len, u32 dist, u32 lane) {
+template <class SRC>
+__device__ __forceinline__ void copy_long_match(u8 *outw, const SRC &src, u32 woff, u32 d, u32 len, u32 dist, u32 lane) {
     const i32 s = (i32)d - (i32)dist;
     if (s >= (i32)woff) {                                       // wave-uniform
         // The whole source lies in the window (19 of 20 long matches on match-heavy data): LDS reads only.  Below, a
@@ -1295,18 +1355,18 @@ __device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 wo
         const i32 q = rep1 ? s : s + (i32)((len & ~3u) + lane); // and its tail byte
         u32 w = 0, t = 0;
         if (lane < nw || rep1) {
-            if (rep1) w = (p < (i32)woff ? gwin[p] : outw[p]) * 0x01010101u;
-            else if (p + 4 <= (i32)woff) __builtin_memcpy(&w, gwin + p, 4);
+            if (rep1) w = (p < (i32)woff ? src.at(p)[0] : outw[p]) * 0x01010101u;
+            else if (p + 4 <= (i32)woff) __builtin_memcpy(&w, src.at(p), 4);
             else if (p >= (i32)woff) w = lds_load32(outw + p);
             else {
                 for (int k = 0; k < 4; k++) {
                     const i32 pk = p + k;
-                    w |= (u32)(pk < (i32)woff ? gwin[pk] : outw[pk]) << (8 * k);
+                    w |= (u32)(pk < (i32)woff ? src.at(pk)[0] : outw[pk]) << (8 * k);
                 }
             }
         }
         if (rep1) t = w;
-        else if (lane < nt) t = q < (i32)woff ? gwin[q] : outw[q];
+        else if (lane < nt) t = q < (i32)woff ? src.at(q)[0] : outw[q];
         if (lane < nw) lds_store32(outw + d + 4 * lane, w);
         if (lane < nt) outw[d + (len & ~3u) + lane] = (u8)t;
         return;
@@ -1321,7 +1381,7 @@ __device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 wo
         if (j < len) {
             const u32 o = j - ((j * rcp) >> 20) * dist;
             const i32 p = s + (i32)o;
-            b[i] = p < (i32)woff ? gwin[p] : outw[p];
+            b[i] = p < (i32)woff ? src.at(p)[0] : outw[p];
         }
     }
 #pragma unroll
@@ -1335,25 +1395,26 @@ __device__ __forceinline__ void copy_long_match(u8 *outw, const u8 *gwin, u32 wo
 // depend on nothing in the batch: up to four of them are fetched together (one dword per lane
 // and match, plus the last len mod 4 bytes), so their HBM/L2 latencies overlap.
 //   mask  lanes of this round that hold such a token; d/len/dist are the lanes' tokens
-__device__ __forceinline__ void copy_independent_long(u8 *outw, const u8 *gwin, u64 mask, u32 d, u32 len, u32 dist, u32 lane) {
+template <class SRC>
+__device__ __forceinline__ void copy_independent_long(u8 *outw, const SRC &src, u64 mask, u32 d, u32 len, u32 dist, u32 lane) {
     while (mask) {
         u32 dd[4], ll[4], w[4], t[4];
-        const u8 *src[4];
+        i32 sp[4];                                              // the sources' window positions
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            ll[k] = 0; dd[k] = 0; src[k] = gwin; w[k] = 0; t[k] = 0;
+            ll[k] = 0; dd[k] = 0; sp[k] = 0; w[k] = 0; t[k] = 0;
             if (mask) {
                 const u32 l = (u32)__ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 dd[k] = lane_get(d, l);
                 ll[k] = lane_get(len, l);
-                src[k] = gwin + ((i32)dd[k] - (i32)lane_get(dist, l));
+                sp[k] = (i32)dd[k] - (i32)lane_get(dist, l);
             }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (4 * lane + 4 <= ll[k]) __builtin_memcpy(&w[k], src[k] + 4 * lane, 4);
-            if (lane < (ll[k] & 3)) t[k] = src[k][(ll[k] & ~3u) + lane];
+            if (4 * lane + 4 <= ll[k]) __builtin_memcpy(&w[k], src.at(sp[k] + (i32)(4 * lane)), 4);
+            if (lane < (ll[k] & 3)) t[k] = src.at(sp[k] + (i32)((ll[k] & ~3u) + lane))[0];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1372,10 +1433,11 @@ struct PreLoad {
     u32 n_sh;       // bytes fetched (0 = nothing to do) | sh << 8
     u32 g;          // bytes of the match that come from before the window (all of them, not just the first 16)
 };
-__device__ __forceinline__ PreLoad pre_load(const u8 *raw, const u8 *gwin, u32 woff, const TokList tl, u32 m, u32 M) {
+template <class SRC>
+__device__ __forceinline__ PreLoad pre_load(const SRC &src, u32 woff, const TokList tl, u32 m, u32 M) {
     PreLoad p;
     p.tok = 0; p.dpos = 0; p.n_sh = 0; p.g = 0;
-    const u8 *pa = raw, *pb = raw;                              // a lane without work reads the chunk's first bytes
+    i32 qa = src.lo(), qb = qa;                                 // a lane without work reads the chunk's first bytes
     if (m < M) {
         const u32 t = tl.tok[m];
         const u32 d = tl.tdst[m];
@@ -1387,24 +1449,24 @@ __device__ __forceinline__ PreLoad pre_load(const u8 *raw, const u8 *gwin, u32 w
             if (g > len) g = len;
             p.g = g;
             const u32 n = g < 16 ? g : 16;
-            const u8 *src = gwin + s;                           // >= raw: dist <= history was checked by the emitter
-            u32 sh = 0;
-            if (n >= 8) { pa = src; pb = src + n - 8; }
+            u32 sh = 0;                                         // (s >= lo(): dist <= history was checked by the emitter)
+            if (n >= 8) { qa = s; qb = s + (i32)n - 8; }
             else {
                 // 8 bytes that END with the wanted ones (never reading past them), clamped to the chunk's start
-                pa = src + n - 8;
-                if (pa < raw) pa = raw;
-                pb = pa;
-                sh = (u32)(src - pa) * 8;
+                qa = s + (i32)n - 8;
+                if (qa < src.lo()) qa = src.lo();
+                qb = qa;
+                sh = (u32)(s - qa) * 8;
             }
             p.n_sh = n | (sh << 8);
         }
     }
-    __builtin_memcpy(&p.a, pa, 8);
-    __builtin_memcpy(&p.b, pb, 8);
+    __builtin_memcpy(&p.a, src.at(qa), 8);
+    __builtin_memcpy(&p.b, src.at(qb), 8);
     return p;
 }
-__device__ __forceinline__ void pre_store(u8 *outw, const u8 *gwin, const PreLoad &p) {
+template <class SRC>
+__device__ __forceinline__ void pre_store(u8 *outw, const SRC &src, const PreLoad &p) {
     u8 *dst = outw + p.dpos;
     const u32 n = p.n_sh & 255, sh = p.n_sh >> 8;
     if (n >= 8) {
@@ -1413,10 +1475,10 @@ __device__ __forceinline__ void pre_store(u8 *outw, const u8 *gwin, const PreLoa
         lds_store32(dst + n - 8, (u32)p.b); no_merge();
         lds_store32(dst + n - 4, (u32)(p.b >> 32));
         if (p.g > 16) {                                         // the rest of a longer one, the plain way (rare)
-            const u8 *src = gwin + ((i32)p.dpos - (i32)((p.tok >> 8) + 1));
+            const i32 s = (i32)p.dpos - (i32)((p.tok >> 8) + 1);
             for (u32 off = 16; off < p.g;) {
                 const u32 k = p.g - off < 16 ? p.g - off : 16;
-                copy16_g2l(dst + off, src + off, k);
+                copy16_g2l(dst + off, src.at(s + (i32)off), k);
                 off += k;
             }
         }
@@ -1457,12 +1519,14 @@ __device__ __forceinline__ u32 pre_compact(const TokList tl, const PreLoad &p, b
 // beyond its foreign source bytes it has written itself.  Matches of LONG_MATCH bytes and more
 // are not copied by their lane: when such a token is the first unresolved one, the whole wave
 // copies it (copy_long_match).
-template <class LDS>
-__device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, LDS &L, const TokList tl, u32 M, u32 lane) {
-    u8 *outw = reinterpret_cast<u8 *>(L.win);               // positions count from the start of L.win
-    const u8 *gwin = raw + base - woff;                         // HBM address of window position 0
+template <class SRC, class LDS>
+__device__ void resolve_tokens(const SRC &src_, u32 cap, u32 woff, LDS &L, const TokList tl_, u32 M, u32 lane) {
+    const SRC src = src_.known();                               // (address spaces spelled out: see in_lds)
+    u8 *outw = in_lds(reinterpret_cast<u8 *>(L.win));       // positions count from the start of L.win
+    TokList tl;
+    tl.tok = in_lds(tl_.tok); tl.tdst = in_lds(tl_.tdst); tl.max = tl_.max;
     u32 rounds = 0;
-    const bool swept = cap >= 8;                                // pre_load may read the chunk's first 8 bytes
+    const bool swept = SRC::always_readable || cap >= 8;        // pre_load may read the chunk's first 8 bytes
     PROF_T0();
     if (swept) {
         u32 K = 0;
@@ -1472,16 +1536,16 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, LDS &
             PreLoad p1, p2, p3;
             p1.a = p1.b = 0; p1.tok = p1.dpos = p1.n_sh = p1.g = 0;
             p2 = p1; p3 = p1;
-            const PreLoad p0 = pre_load(raw, gwin, woff, tl, r0 + lane, M);
-            if (h1) p1 = pre_load(raw, gwin, woff, tl, r0 + 64 + lane, M);
-            if (h2) p2 = pre_load(raw, gwin, woff, tl, r0 + 128 + lane, M);
-            if (h3) p3 = pre_load(raw, gwin, woff, tl, r0 + 192 + lane, M);
+            const PreLoad p0 = pre_load(src, woff, tl, r0 + lane, M);
+            if (h1) p1 = pre_load(src, woff, tl, r0 + 64 + lane, M);
+            if (h2) p2 = pre_load(src, woff, tl, r0 + 128 + lane, M);
+            if (h3) p3 = pre_load(src, woff, tl, r0 + 192 + lane, M);
             wave_sync();                                        // all four rounds' tokens are read before the list is compacted
-            pre_store(outw, gwin, p0);
+            pre_store(outw, src, p0);
             K = pre_compact(tl, p0, r0 + lane < M, K, lane);
-            if (h1) { pre_store(outw, gwin, p1); K = pre_compact(tl, p1, r0 + 64 + lane < M, K, lane); }
-            if (h2) { pre_store(outw, gwin, p2); K = pre_compact(tl, p2, r0 + 128 + lane < M, K, lane); }
-            if (h3) { pre_store(outw, gwin, p3); K = pre_compact(tl, p3, r0 + 192 + lane < M, K, lane); }
+            if (h1) { pre_store(outw, src, p1); K = pre_compact(tl, p1, r0 + 64 + lane < M, K, lane); }
+            if (h2) { pre_store(outw, src, p2); K = pre_compact(tl, p2, r0 + 128 + lane < M, K, lane); }
+            if (h3) { pre_store(outw, src, p3); K = pre_compact(tl, p3, r0 + 192 + lane < M, K, lane); }
         }
         wave_sync();
         M = K;
@@ -1505,10 +1569,9 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, LDS &
             u32 g = (u32)((i32)woff - s);
             if (g > rem) g = rem;
             if (!swept) {
-                const u8 *src = gwin + s;                       // >= raw: dist <= history was checked by the emitter
-                for (u32 off = 0; off < g;) {
+                for (u32 off = 0; off < g;) {                   // (s >= lo(): dist <= history was checked by the emitter)
                     const u32 n = g - off < 16 ? g - off : 16;
-                    copy16_g2l(outw + cur + off, src + off, n);
+                    copy16_g2l(outw + cur + off, src.at(s + (i32)off), n);
                     off += n;
                 }
             }
@@ -1520,7 +1583,7 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, LDS &
             const u64 im = __ballot(indep);
             if (im) {
                 PROF_CNT(PF_N_INDEP, (u32)__popcll(im), lane);
-                copy_independent_long(outw, gwin, im, d, len, dist, lane);
+                copy_independent_long(outw, src, im, d, len, dist, lane);
                 wave_sync();
             }
         }
@@ -1558,7 +1621,7 @@ __device__ void resolve_tokens(const u8 *raw, u32 cap, u32 base, u32 woff, LDS &
 #ifdef XFG_PROFILE
                 const unsigned long long tl0_ = __builtin_amdgcn_s_memtime();
 #endif
-                copy_long_match(outw, gwin, woff, (u32)water, lane_get(len, first), lane_get(dist, first), lane);
+                copy_long_match(outw, src, woff, (u32)water, lane_get(len, first), lane_get(dist, first), lane);
                 if (lane == first) pending = false;
                 wave_sync();
 #ifdef XFG_PROFILE
@@ -1633,7 +1696,15 @@ __device__ __forceinline__ u32 seg_bits_for(u32 out_bytes, u32 in_bits) {
 // (WG = true: called by wave 0 of the workgroup-per-chunk kernel for the stretches its waves do not share -- batches
 // near the end of the stream, blocks without a distance code, serial batches, anything that ended a group with an
 // error: decodes at least one batch and returns XFG_ST_AGAIN at the first batch that is an ordinary parallel one.)
+#ifndef XFG_WG_KEEP_SHORT
+#define XFG_WG_KEEP_SHORT 1             // match-heavy batches (short segments) stay with wave 0 as well: repeats kind 65 -> 77 GB/s at 768 chunks
+#endif
 constexpr int XFG_ST_AGAIN = -100;                              // never leaves the kernel
+// Segments of XFG_SEG_RUN bits follow a batch whose output was nearly all long matches or runs (seg_bits_for).
+__device__ __forceinline__ bool wg_keeps(u32 seg_bits) {
+    return !XFG_SEG_BITS && (u32)XFG_SEG_RUN != (u32)XFG_SEG_LONG && (u32)XFG_SEG_RUN != (u32)XFG_SEG_MID && (u32)XFG_SEG_RUN != (u32)XFG_SEG_SHORT &&
+           (seg_bits == (u32)XFG_SEG_RUN || (XFG_WG_KEEP_SHORT && seg_bits == (u32)XFG_SEG_SHORT));
+}
 template <bool WG = false, class LDS>
 __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 lane, u32 p0,
                                          int lit_state, int dist_state, u32 spec_back, u32 max_fix, u32 &seg_bits,
@@ -1650,7 +1721,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
     bool serial = WG && serial_init;                            // output-bound stretch (long matches): lane 0 decodes alone
     for (u32 nbatch = 0;; nbatch++) {
         if (nbatch > total_bits + 4) { be.status = XFG_ST_INTERNAL; be.bitpos = p0; return be; }   // every batch consumes >= 1 bit
-        if (WG && nbatch > 0 && !dist_empty && !force_tail && !serial && p0 + 64u <= total_bits) { be.status = XFG_ST_AGAIN; be.bitpos = p0; return be; }
+        // (batches of runs and long matches stay with wave 0: their write-out is all there is to them, and a group's write-outs are serial)
+        if (WG && nbatch > 0 && !dist_empty && !force_tail && !serial && p0 + 64u <= total_bits && !wg_keeps(seg_bits)) { be.status = XFG_ST_AGAIN; be.bitpos = p0; return be; }
         // ---- compressed window of this batch (fetched during the previous batch's stage 2 when there was one)
         const i32 wb0 = (i32)(((stream0 + (p0 >> 3)) & ~(i64)15) - stream0);
         {
@@ -1901,7 +1973,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
                 PROF_T0();
                 mem_sync();                                     // earlier rounds' flushed bytes are read back here
                 PROF_ADD(PF_R_SYNC, lane);
-                resolve_tokens(o.raw, o.cap, o.pos, ob + wo, L, tlr, M, lane);
+                const SrcHbm hbm{o.raw + o.pos - (ob + wo), (i32)(ob + wo) - (i32)o.pos};
+                resolve_tokens(hbm, o.cap, ob + wo, L, tlr, M, lane);
                 PROF_ADD(PF_RESOLVE, lane);
             }
             // ---- flush to HBM (never beyond the chunk's capacity)
@@ -2318,7 +2391,7 @@ int wg_blocks_per_cu(int waves)
 {
     int nb = g_wg_per_cu[waves].load(std::memory_order_relaxed);
     if (nb > 0) return nb;
-    const size_t lds = xfg::wg_lds_bytes((uint32_t)waves, xfg::wg_extra_bytes((uint32_t)waves));
+    const size_t lds = xfg::wg_lds_bytes((uint32_t)waves, xfg::wg_extra_bytes((uint32_t)waves), xfg::wg_has_ring((uint32_t)waves));
     // more than 64 KB of dynamic LDS has to be asked for
     (void)hipFuncSetAttribute((const void *)xfg::inflate_chunks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xfg::WG_LDS_MAX);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg_kernel, 64 * waves, lds) != hipSuccess || nb < 1) nb = 1;
@@ -2340,9 +2413,11 @@ extern "C" int xfg_decode_waves_for(uint32_t n, int num_cu)
     const int forced = decode_waves_setting();
     if (forced) return forced;
     const uint64_t slots = (uint64_t)num_cu * (uint64_t)blocks_per_cu();     // waves the chip holds
-    uint64_t w = n ? slots / n : 1;
-    if (w > (uint64_t)xfg::WG_MAX_WAVES) w = xfg::WG_MAX_WAVES;
-    return w < 2 ? 1 : (int)w;
+    const uint64_t w = n ? slots / n : 1;
+    // Measured (profiles/r3/wg_wave_sweep.txt): 12 waves (one workgroup per CU, the history ring in LDS) where the
+    // chunks are few enough for that; otherwise 4 (four workgroups per CU) -- 5 to 8 waves per chunk lose to 4 on
+    // every shape; 3 or 2 when there are more chunks than that.
+    return w >= 12 ? 12 : w >= 4 ? 4 : w >= 2 ? (int)w : 1;
 }
 
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, const void *d_chunks, uint32_t n,
@@ -2357,9 +2432,10 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, co
         uint32_t blocks = (uint32_t)num_cu * (uint32_t)wg_blocks_per_cu(waves);
         if (blocks > n) blocks = n;
         const uint32_t extra = xfg::wg_extra_bytes((uint32_t)waves);
-        hipLaunchKernelGGL(xfg::inflate_chunks_wg_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves, extra), stream,
+        const bool ring = xfg::wg_has_ring((uint32_t)waves);
+        hipLaunchKernelGGL(xfg::inflate_chunks_wg_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves, extra, ring), stream,
                            (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
-                           (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch, extra);
+                           (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch, extra, ring ? 1u : 0u);
         return hipGetLastError();
     }
     const uint32_t blocks = xfg_grid_blocks(n, num_cu);

@@ -1,6 +1,6 @@
 """The workgroup-per-chunk decode mode (compress_amd/csrc/inflate_wg_kernel.inc), forced with xfg_set_decode_waves:
 the same golden vectors, generated streams and damaged chunks as tests/test_gpu_parity.py must come out bit-identical
-(bytes, InputOffset, OutputOffset, status) with 2, 4, 5 and 16 wavefronts per chunk, and identical to what one
+(bytes, InputOffset, OutputOffset, status) with 2, 4, 5, 12 and 16 wavefronts per chunk (12 and 16: with the LDS history ring), and identical to what one
 wavefront per chunk gives.  Reference shapes: flate/reader_test.go:835-859 and :981-1009 (one stream, one reader),
 xflate/reader_test.go:277-301 and :568-609 (a Reader that decodes a few chunks per call)."""
 import random
@@ -14,7 +14,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 FLATE = load_golden("flate_reader.json")["vectors"]
-WAVES = [2, 4, 5, 16]
+WAVES = [2, 4, 5, 12, 16]
 
 
 @pytest.fixture(scope="module")
@@ -47,7 +47,7 @@ def test_setting_is_checked():
     assert L.xfg_set_decode_waves(-1) == capi.XFG_E_ARG
     assert L.xfg_set_decode_waves(0) == capi.XFG_OK
     # by chunk count: one wavefront per chunk from half the wave slots on, a workgroup below
-    assert L.xfg_decode_waves_for(1, 256) == 16
+    assert L.xfg_decode_waves_for(1, 256) == 12
     assert L.xfg_decode_waves_for(1024, 256) in (2, 3, 4)
     assert L.xfg_decode_waves_for(1 << 14, 256) == 1
     assert L.xfg_set_decode_waves(3) == capi.XFG_OK

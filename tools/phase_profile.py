@@ -18,8 +18,7 @@ NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "
          "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix",
          "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "t_sort", "t_root", "t_sub",
          "n_wfull", "n_wf_tok", "n_wf_out", "n_long", "n_long_g", "t_long", "n_indep", "n_long_rdy",
-         "w_chain", "w_cnt", "w_out", "w_water", "w_groups", "w_abort", "w_alone", "w_refix",
-         "d0", "d1", "d2", "d3", "d4", "d5", "d6", "d7"]
+         "w_chain", "w_cnt", "w_out", "w_water", "w_groups", "w_abort", "w_alone", "w_refix"]
 
 
 def main():
@@ -33,13 +32,13 @@ def main():
         d_raw = torch.zeros(shard["raw_len"] + 64, dtype=torch.uint8, device=dev)
         d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
         L = capi.lib()
-        buf = (ctypes.c_ulonglong * 56)()
+        buf = (ctypes.c_ulonglong * 48)()
         for it in range(2):
-            L.xfg_debug_profile(buf, 56)          # clear
+            L.xfg_debug_profile(buf, 48)          # clear
             ctx.decode_device(d_comp.data_ptr(), len(shard["comp"]), d_chunks.data_ptr(), n,
                               d_raw.data_ptr(), shard["raw_len"], d_res.data_ptr(), None)
             ctx.sync()
-        L.xfg_debug_profile(buf, 56)
+        L.xfg_debug_profile(buf, 48)
         v = {k: buf[i] for i, k in enumerate(NAMES)}
         tot = max(v["total"], 1)
         print("== %s: %d chunks" % (w, n))
@@ -70,8 +69,6 @@ def main():
             print("  workgroup mode (waves per chunk: %d): wave-cycles waiting for the wave before: chain %.0f, count %.0f; for the group's outcome %.0f; "
                   "for the water mark %.0f per batch; group calls %d, aborted %d, stretches wave 0 decoded alone %d, chains repaired after the wave before settled %d" %
                   (L.xfg_decode_waves_for(n, 256), v["w_chain"] / nb, v["w_cnt"] / nb, v["w_out"] / nb, v["w_water"] / nb, ng, v["w_abort"], v["w_alone"], v["w_refix"]))
-        if v["d0"]:
-            print("  debug:", " ".join("%s=%.2f" % (k, v[k] / v["d0"]) for k in ("d1", "d2", "d3", "d4", "d5", "d6", "d7")), "per d0 =", v["d0"])
         ctx.close()
 
 
