@@ -40,14 +40,17 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 
 def measured_traffic(workload):
-    """Fabric-side bytes per launch from the committed rocprofv3 counter passes (profiles/r2/traffic.json), or None.
+    """Fabric-side bytes per launch from the committed rocprofv3 counter passes (profiles/r3/traffic.json, collected by
+    tools/traffic_pass.sh with this same bench.py command per workload), or None.
     FETCH_SIZE counts the narrow match-source loads 1 : 1 (64 bytes per scattered load) and the wide coalesced reads of the
     compressed bytes at half (calibrated: profiles/r2/calibration_narrow_loads.txt), WRITE_SIZE is exact; both in KB."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r2", "traffic.json")))[workload]
-        return int((t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024 + t["comp_bytes"] // 2)
-    except (OSError, KeyError, ValueError):
-        return None
+    for rnd in ("r3", "r2"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))[workload]
+            return int((t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024 + t["comp_bytes"] // 2)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 WORKLOADS = {
     # name: (chunks per GPU, chunk size, kinds, zlib level, distinct chunks generated)
@@ -341,9 +344,9 @@ def main():
         step()
     torch.cuda.synchronize(dev)
 
-    # parity gate (untimed): every chunk ok, sizes as promised, bytes equal to the generator's raw data
-    verified = None
-    if not args.no_verify:
+    # parity gate (untimed; before the timed loop and once more after it, on what the LAST timed step left in HBM):
+    # every chunk ok, sizes as promised, bytes equal to the generator's raw data
+    def verify(when):
         import numpy as np
         res = d_res.cpu().numpy().view("i4,u4,i8,i8")
         want_out = np.array([shard["descs"][i].raw_size for i in range(n)], dtype=np.int64)
@@ -357,11 +360,18 @@ def main():
         eq = True
         for lo in range(0, nv, 2048):                         # bounded temporaries
             eq = eq and bool(torch.equal(got[lo:lo + 2048], distinct[idx[lo:lo + 2048]]))
-        verified = ok and eq
         del distinct
-        if not verified:
-            print(json.dumps({"error": "parity check failed on rank %d" % rank, "status_ok": ok, "bytes_equal": eq}))
+        if not (ok and eq):
+            print(json.dumps({"error": "parity check failed on rank %d (%s the timed loop)" % (rank, when), "status_ok": ok, "bytes_equal": eq}))
             sys.exit(1)
+        return True
+
+    verified = None
+    if not args.no_verify:
+        verified = verify("before")
+        d_raw.zero_()                                         # the timed steps have to write every byte again
+        d_res.zero_()
+        torch.cuda.synchronize(dev)
 
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
@@ -373,6 +383,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / max(args.steps, 1)
+    if not args.no_verify and args.steps > 0:
+        verified = verify("after")
 
     sum_raw, sum_comp = float(raw_len), float(comp_len)
     if dist is not None:
@@ -392,6 +404,8 @@ def main():
         # against n_gpus x 8 TB/s
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 / world
         n_chunks, chunk_size, kinds, level, nd = WORKLOADS[args.workload]
+        # one wavefront per chunk, or a workgroup per chunk when the launch has few chunks (xfg_set_decode_waves)
+        waves_per_chunk = int(capi.lib().xfg_decode_waves_for(n, torch.cuda.get_device_properties(dev).multi_processor_count))
         out = {
             "metric": "decompressed GB/s (node), xflate decode",
             "value": round(value, 3),
@@ -421,7 +435,8 @@ def main():
                         "ratio": round(raw_len / comp_len, 3), "verified_bit_exact": verified}),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload),
-                         "kernel": "inflate_chunks_kernel", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "inflate_chunks_kernel" if waves_per_chunk == 1 else "inflate_chunks_wg_kernel",
+                         "waves_per_chunk": waves_per_chunk, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes if world == 1 else int(algo_bytes / world),
                          "per": "GPU (achieved and peak are per GPU; launches of all ranks run side by side)"},
         }

@@ -8,6 +8,7 @@ package amd
 import "C"
 
 import (
+	"runtime"
 	"unsafe"
 
 	"github.com/dsnet/compress/internal/errors"
@@ -63,6 +64,9 @@ func DecodeAll(device int, stream []byte, shard, nShards int) (raw []byte, rawSt
 		return nil, 0, nil, errorf(errors.Internal, C.GoString(C.xfg_strerror(rc)))
 	}
 	defer C.xfg_destroy(ctx)
+	// (the error text is per OS thread: stay on this one until it has been fetched)
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	rc := C.xfg_decode(ctx, sp, C.size_t(len(stream)), &mine[0], C.size_t(len(mine)),
 		(*C.uint8_t)(unsafe.Pointer(&raw[0])), C.size_t(rawLen), &cres[0])
 	if rc != C.XFG_OK {

@@ -83,6 +83,14 @@ var (
 
 // classErr maps an XFG_ERR_* class to the reference's error values
 // (internal/errors/errors.go:36-56, xflate/common.go:114-134).
+// xfg_last_error() is per OS thread (a thread_local in the library), and the Go scheduler may move a goroutine to
+// another thread between two cgo calls: every method that may end in classErr pins its goroutine to its thread for
+// the length of the call (pinned), so that the text fetched is the failing call's.
+func pinned() func() {
+	runtime.LockOSThread()
+	return runtime.UnlockOSThread
+}
+
 func classErr(c C.int) error {
 	switch c {
 	case C.XFG_ERR_NONE:
@@ -129,6 +137,7 @@ func NewReader(rs io.ReadSeeker, conf *ReaderConfig) (*Reader, error) {
 // (syscall.Mmap), C memory -- and stays valid until the Reader is freed: the library reads it where it lies, no
 // callbacks (xfg_reader_new_mem).  Do not pass memory of the Go heap: C keeps the pointer after the call returns.
 func NewReaderMem(stream unsafe.Pointer, n int, conf *ReaderConfig) (*Reader, error) {
+	defer pinned()()
 	dev := 0
 	if conf != nil {
 		dev = conf.Device
@@ -144,6 +153,7 @@ func NewReaderMem(stream unsafe.Pointer, n int, conf *ReaderConfig) (*Reader, er
 
 // Reset mirrors (*xflate.Reader).Reset (reader.go:124-157).
 func (xr *Reader) Reset(rs io.ReadSeeker) error {
+	defer pinned()()
 	if xr.h != 0 {
 		xr.h.Delete()
 	}
@@ -161,6 +171,7 @@ func (xr *Reader) Reset(rs io.ReadSeeker) error {
 
 // Read mirrors (*xflate.Reader).Read (reader.go:162-215).
 func (xr *Reader) Read(buf []byte) (int, error) {
+	defer pinned()()
 	if len(buf) == 0 {
 		return 0, nil
 	}
@@ -171,6 +182,7 @@ func (xr *Reader) Read(buf []byte) (int, error) {
 
 // Seek mirrors (*xflate.Reader).Seek (reader.go:221-279).
 func (xr *Reader) Seek(offset int64, whence int) (int64, error) {
+	defer pinned()()
 	if whence < 0 || whence > 2 {
 		whence = 99 // the C side reports errors.Invalid
 	}
@@ -180,7 +192,10 @@ func (xr *Reader) Seek(offset int64, whence int) (int64, error) {
 }
 
 // Close mirrors (*xflate.Reader).Close (reader.go:282-291): idempotent, returns the sticky error.
-func (xr *Reader) Close() error { return classErr(C.xfg_reader_close(xr.r)) }
+func (xr *Reader) Close() error {
+	defer pinned()()
+	return classErr(C.xfg_reader_close(xr.r))
+}
 
 // SetWindow bounds how many decoded bytes one device launch may produce ahead of the reads
 // (default 256 MiB).  After a Seek the window restarts at one chunk and doubles while reads stay

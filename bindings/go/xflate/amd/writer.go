@@ -11,6 +11,7 @@ import (
 	"encoding/binary"
 	"hash/crc32"
 	"io"
+	"runtime"
 	"unsafe"
 
 	"github.com/dsnet/compress/internal/errors"
@@ -149,6 +150,9 @@ func (xw *Writer) deflate(chunks [][]byte) ([][]byte, error) {
 	if len(raw) > 0 {
 		rp = (*C.uint8_t)(unsafe.Pointer(&raw[0]))
 	}
+	// (the error text is per OS thread: stay on this one until it has been fetched)
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	rc := C.xfg_deflate(xw.ctx, rp, C.size_t(len(raw)), &desc[0], C.size_t(len(desc)),
 		(*C.uint8_t)(unsafe.Pointer(&comp[0])), C.size_t(co), &res[0])
 	if rc != C.XFG_OK {

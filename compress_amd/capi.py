@@ -110,6 +110,22 @@ def lib():
     return L
 
 
+_hooks = None
+
+
+def testhooks_lib():
+    """libxflate_amd_testhooks.so: host_reader.cpp built once more with the test hooks of include/xflate_amd_testhooks.h
+    (tests only; the shipped library does not export them)."""
+    global _hooks
+    if _hooks is None:
+        lib()                                           # the hooks library is linked against the shipped one
+        path = os.path.join(os.path.dirname(LIB_PATH), "libxflate_amd_testhooks.so")
+        if not os.path.exists(path):
+            raise ImportError("libxflate_amd_testhooks.so not built: run `make -C compress_amd/csrc`")
+        _hooks = ctypes.CDLL(path)
+    return _hooks
+
+
 class TransportError(RuntimeError):
     pass
 

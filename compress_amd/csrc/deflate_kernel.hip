@@ -287,17 +287,25 @@ __device__ bool run_pass(WaveLds &L, const u8 *src, u32 n, u32 *out32, Tail &t, 
         } else {
             // ---- 4b. code the tokens: literal/length code and its extra bits, distance code and its extra bits
             u32 bits_a = 0, na = 0, bits_b = 0, nbb = 0;
+            bool uncoded = false;                               // a symbol the counting pass did not see: its code has no bits
             if (mine) {
                 if (mlen) {
                     const MatchSyms ms = match_syms(mlen, mdist);
                     const u32 ca = L.code[257 + ms.s], cb = L.code[NLL + ms.ds];
+                    uncoded = (ca >> 16) == 0 || (cb >> 16) == 0;
                     na = ca >> 16; bits_a = (ca & 0xffff) | (ms.x << na); na += ms.e;          // <= 15 + 5
                     nbb = cb >> 16; bits_b = (cb & 0xffff) | (ms.dx << nbb); nbb += ms.de;     // <= 15 + 13
                 } else {
                     const u32 ca = L.code[src[p]];
+                    uncoded = (ca >> 16) == 0;
                     na = ca >> 16; bits_a = ca & 0xffff;
                 }
             }
+            // This pass replays the counting pass's LZ77 decisions, which hang on which lane wins a same-address write
+            // to the hash table -- not an ordered thing.  Should the two passes ever part, a token's symbol may have no
+            // code; writing it would drop the token silently (status OK, wrong bytes).  Give the chunk up instead: the
+            // caller writes it as stored blocks.
+            if (__ballot(uncoded)) return false;
             const u32 nb = na + nbb;
             // exclusive prefix sum of nb over the wave
             u32 incl = nb;

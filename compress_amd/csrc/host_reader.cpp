@@ -926,7 +926,10 @@ extern "C" int xfg_index_parse(const uint8_t *stream, size_t len, xfg_chunk *chu
 
 // ------------------------------------------------------------ test hooks ---
 // include/xflate_amd_testhooks.h: the reference's unit-test vectors for meta.Reader and index reach the
-// C++ above through these, not through whole streams.
+// C++ above through these, not through whole streams.  Not part of libxflate_amd.so: `make` builds this file a
+// second time with -DXFG_TEST_HOOKS into libxflate_amd_testhooks.so (linked against the library), which only
+// tests/test_host_cpp_vectors.py loads.
+#ifdef XFG_TEST_HOOKS
 #include "../../include/xflate_amd_testhooks.h"
 
 extern "C" int xfg_test_meta_block(const uint8_t *in, size_t len, uint8_t *out, size_t *out_len, int *final, int64_t *in_off) {
@@ -989,6 +992,7 @@ extern "C" int xfg_test_decode_index(const uint8_t *enc, size_t len, void *idx, 
     if (back_size) *back_size = ix->back_size;
     return e;
 }
+#endif  // XFG_TEST_HOOKS
 
 // Index-range sharding: cut the chunk table into n_shards contiguous
 // record ranges of about equal work, work = comp_size + raw_size (the bytes a GPU reads and

@@ -84,8 +84,15 @@ struct HostPool {
     std::vector<std::function<void()> > q;
     size_t running;
     bool stop;
+    // Throws (std::system_error, std::bad_alloc) if not even one thread can be started; the threads that were
+    // started before a failure are kept (make_pool() below is the only caller and catches).
     explicit HostPool(int n) : running(0), stop(false) {
-        for (int i = 0; i < n; i++) threads.emplace_back([this] { work(); });
+        try {
+            threads.reserve((size_t)n);
+            for (int i = 0; i < n; i++) threads.emplace_back([this] { work(); });
+        } catch (...) {
+            if (threads.empty()) throw;                         // (a vector of joinable threads must not be destroyed: none here)
+        }
     }
     ~HostPool() {
         { std::lock_guard<std::mutex> l(m); stop = true; }
@@ -108,11 +115,26 @@ struct HostPool {
             cv_idle.notify_all();
         }
     }
-    void submit(std::function<void()> f) {
-        { std::lock_guard<std::mutex> l(m); q.push_back(std::move(f)); }
+    // false: the task could not be queued (out of memory) and was not run
+    bool submit(std::function<void()> f) noexcept {
+        try {
+            { std::lock_guard<std::mutex> l(m); q.push_back(std::move(f)); }
+        } catch (...) {
+            return false;
+        }
         cv.notify_one();
+        return true;
     }
 };
+// No exception may cross the extern "C" entry points: thread creation fails with std::system_error when the
+// process is at its thread limit (the GPU box grants 16 CPUs per GPU), allocation with std::bad_alloc.
+static HostPool *make_pool(int n) noexcept {
+    try {
+        return new HostPool(n);
+    } catch (...) {
+        return nullptr;
+    }
+}
 
 struct xfg_ctx {
     int device;
@@ -126,6 +148,7 @@ struct xfg_ctx {
     void *h_res[8];                       // pinned per-slot copies of the slice's results
     void *h_up[4];                        // pinned upload slots (a slice's compressed bytes)
     HostPool *pool;
+    int pipe_setup_failures;              // decode_pipelined: set-ups that could not get their pinned memory, streams or threads
     void *d_scratch;      // the chunk counters of the persistent grid (xfg_scratch_bytes: 2 KB, allocated once)
     // reusable device staging for the host-pointer path
     void *d_comp; size_t comp_cap;
@@ -254,6 +277,7 @@ const int kUpSlots = 4;
 const int kDownSlots = 8;
 const int kCopyThreads = 8;
 const size_t kSliceChunks = 65536;        // chunks per slice at most (sizes the pinned result slots)
+const int kSetupTries = 3;                // failed set-ups of the pipeline's parts before a context stops trying
 
 struct Slice { size_t a, b; size_t comp_lo, comp_hi, raw_lo, raw_hi; size_t unit; };
 struct Unit { size_t s0, s1; };           // slices [s0, s1)
@@ -274,7 +298,13 @@ void parallel_copy(HostPool *pool, uint8_t *dst, const uint8_t *src, size_t len)
     for (; off < len; off += per) {
         const size_t k = std::min(per, len - off);
         left++;
-        pool->submit([=, &left, &m, &cv] { memcpy(dst + off, src + off, k); std::lock_guard<std::mutex> l(m); left--; cv.notify_one(); });   // (notify under the lock: cv lives on the waiter's stack)
+        // (notify under the lock: cv lives on the waiter's stack; a piece that cannot be queued is copied here)
+        bool queued = false;
+        try {
+            queued = pool->submit([=, &left, &m, &cv] { memcpy(dst + off, src + off, k); std::lock_guard<std::mutex> l(m); left--; cv.notify_one(); });
+        } catch (...) {                                         // (constructing the std::function may allocate)
+        }
+        if (!queued) { memcpy(dst + off, src + off, k); left--; }
     }
     memcpy(dst, src, std::min(per, len));
     std::unique_lock<std::mutex> l(m);
@@ -295,7 +325,7 @@ struct EventBag {
 
 // A large host-to-host copy on the context's helper threads (the Reader's copy into the caller's buffer).
 extern "C" void xfg_host_copy(xfg_ctx *c, void *dst, const void *src, size_t n) {
-    if (c && n >= (4u << 20) && !c->pool) c->pool = new (std::nothrow) HostPool(kCopyThreads + 1);
+    if (c && n >= (4u << 20) && !c->pool) c->pool = make_pool(kCopyThreads + 1);
     if (!c || !c->pool || n < (4u << 20)) { memcpy(dst, src, n); return; }
     parallel_copy(c->pool, (uint8_t *)dst, (const uint8_t *)src, n);
 }
@@ -335,22 +365,30 @@ static int decode_pipelined(xfg_ctx *c, const uint8_t *comp, size_t comp_len, co
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double T0 = now();
     std::vector<double> t_up0(ns), t_up1(ns), t_dl(ns), t_f0(ns), t_f1(ns), t_f2(ns);
-    // ---- one-time set-up of the context's pipeline parts
-    for (int k = 0; k < kDownSlots; k++)
-        if (!c->h_slot[k]) {
-            HIP_TRY(hipHostMalloc(&c->h_slot[k], kSliceRaw + 64, hipHostMallocDefault));
-            HIP_TRY(hipHostMalloc(&c->h_res[k], kSliceChunks * sizeof(xfg_result), hipHostMallocDefault));
-        }
-    for (int k = 0; k < kUpSlots; k++)
-        if (!c->h_up[k]) HIP_TRY(hipHostMalloc(&c->h_up[k], kSliceRaw + 64, hipHostMallocDefault));
+    // ---- one-time set-up of the context's pipeline parts.  Each part is made and checked on its own (a call that
+    // failed half-way leaves the parts it made; the next call makes the rest).  The plain path needs none of them
+    // (192 MiB of pinned host memory, three more streams, helper threads): a part that cannot be had sends this
+    // call and, once it has failed kSetupTries times, every later one there.
+    if (c->pipe_setup_failures >= kSetupTries) return -1;
     const int lanes = kLanes;
-    for (int k = 1; k < lanes; k++)
-        if (!c->stream_k[k]) HIP_TRY(hipStreamCreateWithFlags(&c->stream_k[k], hipStreamNonBlocking));
-    c->stream_k[0] = c->stream;
-    if (!c->stream_up) HIP_TRY(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
-    if (!c->stream_dl) HIP_TRY(hipStreamCreateWithFlags(&c->stream_dl, hipStreamNonBlocking));
-    if (!c->d_scratch_k) HIP_TRY(hipMalloc(&c->d_scratch_k, kLanes * xfg_scratch_bytes(c->num_cu)));
-    if (!c->pool) { c->pool = new (std::nothrow) HostPool(kCopyThreads + 1); if (!c->pool) return XFG_E_NOMEM; }
+    {
+        bool ok = true;
+        auto need = [&](hipError_t e) { if (e != hipSuccess) { ok = false; (void)hipGetLastError(); } };
+        for (int k = 0; k < kDownSlots && ok; k++) {
+            if (!c->h_slot[k]) need(hipHostMalloc(&c->h_slot[k], kSliceRaw + 64, hipHostMallocDefault));
+            if (ok && !c->h_res[k]) need(hipHostMalloc(&c->h_res[k], kSliceChunks * sizeof(xfg_result), hipHostMallocDefault));
+        }
+        for (int k = 0; k < kUpSlots && ok; k++)
+            if (!c->h_up[k]) need(hipHostMalloc(&c->h_up[k], kSliceRaw + 64, hipHostMallocDefault));
+        for (int k = 1; k < lanes && ok; k++)
+            if (!c->stream_k[k]) need(hipStreamCreateWithFlags(&c->stream_k[k], hipStreamNonBlocking));
+        c->stream_k[0] = c->stream;
+        if (ok && !c->stream_up) need(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
+        if (ok && !c->stream_dl) need(hipStreamCreateWithFlags(&c->stream_dl, hipStreamNonBlocking));
+        if (ok && !c->d_scratch_k) need(hipMalloc(&c->d_scratch_k, kLanes * xfg_scratch_bytes(c->num_cu)));
+        if (ok && !c->pool) { c->pool = make_pool(kCopyThreads + 1); ok = c->pool != nullptr; }
+        if (!ok) { c->pipe_setup_failures++; return -1; }
+    }
     const size_t scratch_each = xfg_scratch_bytes(c->num_cu);
     EventBag bag;
     std::vector<hipEvent_t> ev_d(ns), ev_h(ns), ev_k(nu);
@@ -376,7 +414,9 @@ static int decode_pipelined(xfg_ctx *c, const uint8_t *comp, size_t comp_len, co
     size_t launched = 0;                                        // units whose kernel is enqueued
     hipError_t up_err = hipSuccess;
     bool up_done = false, stop = false;
-    c->pool->submit([&] {
+    bool fed_ok = false;
+    try {
+    fed_ok = c->pool->submit([&] {
         (void)hipSetDevice(c->device);
         hipError_t e = hipSuccess;
         for (size_t u = 0; u < nu && e == hipSuccess; u++) {
@@ -413,6 +453,13 @@ static int decode_pipelined(xfg_ctx *c, const uint8_t *comp, size_t comp_len, co
         up_err = e; up_done = true;
         cv.notify_all();
     });
+    } catch (...) {                                             // (the std::function's allocation)
+    }
+    if (!fed_ok) {
+        // nothing but the chunk table's upload has been enqueued: let it land, then the plain path takes the call
+        (void)hipStreamSynchronize(c->stream);
+        return -1;
+    }
     // ---- the calling thread: downloads as slots fall free, then slice j's bytes from its slot to the caller
     hipError_t herr = hipSuccess;
     size_t next_dl = 0;                                         // the next slice whose download is to be enqueued
@@ -509,7 +556,14 @@ extern "C" int xfg_decode(xfg_ctx *c, const uint8_t *comp, size_t comp_len,
     // large batches in stream order take the pipelined path (uploads, kernels, downloads and host copies overlap)
     static const bool no_pipeline = [] { const char *e = getenv("XFG_NO_PIPELINE"); return e && *e && *e != '0'; }();   // (tests compare the two paths)
     if (!no_pipeline && raw_len >= kPipelineMin && n <= (1u << 30) && stream_ordered(chunks, n)) {
-        rc = decode_pipelined(c, comp, comp_len, chunks, n, raw, raw_len, res);
+        // (every allocation of decode_pipelined that can throw -- its vectors, the event bag -- comes before its feeder
+        // task is queued: an exception means that nothing has been started, and the plain path takes the call)
+        try {
+            rc = decode_pipelined(c, comp, comp_len, chunks, n, raw, raw_len, res);
+        } catch (...) {
+            (void)hipStreamSynchronize(c->stream);
+            rc = -1;
+        }
         if (rc >= 0) return rc;
     }
     if (comp_len) HIP_TRY(hipMemcpyAsync(c->d_comp, comp, comp_len, hipMemcpyHostToDevice, c->stream));

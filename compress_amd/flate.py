@@ -26,15 +26,19 @@ class Reader(object):
     The source may be bytes-like or a readable object.  The "never read more than necessary" contract of
     compress.ByteReader / compress.BufferedReader (api.go:29-72; canary test flate/flate_test.go:70-92, sync test
     :124-203) is kept like this, the device being a batch decoder that wants all the input it can get:
-      peekable source (has peek(), the analogue of BufferedReader: io.BufferedReader) -- input is looked at with
-          peek() and consumed with read() only up to InputOffset, so a byte after the final block stays unread;
-      seekable source (seek()/tell(): BytesIO, files) -- read ahead in blocks, then seek back to the byte after
-          the stream (the un-read);
+      seekable source (seek()/tell(): BytesIO, files -- also when it has peek(), as open(path, "rb") has) -- read
+          ahead in blocks, then seek back to the byte after the stream (the un-read);
+      peekable source that cannot seek (has peek(), the analogue of BufferedReader: a buffered pipe) -- input is
+          looked at with peek() and consumed with read() only up to InputOffset, so a byte after the final block
+          stays unread;
       any other readable -- read ahead in blocks as the reference's own bufio wrapper does for a plain io.Reader
           (internal/prefix/reader.go:103-109); no promise about bytes after the stream.
     Input is pulled only when every decoded byte has been handed out, so a stream that ends in a sync flush is
     delivered up to the flush without another read of the source (TestSync).  Every pull decodes the stream
-    from its start again (the kernel has no resume state): fine for a few flushes, quadratic for many.
+    from its start again (the kernel has no resume state), so a seekable source is read in blocks that double
+    (1 MiB, 2 MiB, ...): a stream of n bytes is decoded about log2(n / 1 MiB) times and at most twice its length
+    in all.  A source that cannot seek is pulled as it delivers (a pipe's reader must not wait for more than the
+    writer has flushed), which is quadratic in the number of pulls: meant for streams of a few flushes.
     """
     BLOCK = 1 << 20
 
@@ -52,6 +56,9 @@ class Reader(object):
         self._start = 0
         self._src_eof = True
         self._ctx = None
+        self._block = self.BLOCK  # bytes asked of a seekable source next
+        self._outbuf = None       # reused output buffer
+        self.decodes = 0          # calls of xfg_flate_decode so far (tests)
 
     def Reset(self, r, ctx=None):
         """Reset (reader.go:45-56)."""
@@ -59,11 +66,12 @@ class Reader(object):
         self._ctx = ctx or default_context()
         if hasattr(r, "read"):
             self._src, self._src_eof = r, False
-            if hasattr(r, "peek"):
-                self._kind = "peek"
-            elif hasattr(r, "seek") and hasattr(r, "tell") and (not hasattr(r, "seekable") or r.seekable()):
+            seekable = hasattr(r, "seek") and hasattr(r, "tell") and (not hasattr(r, "seekable") or r.seekable())
+            if seekable:
                 self._kind = "seek"
                 self._start = r.tell()
+            elif hasattr(r, "peek"):
+                self._kind = "peek"
             else:
                 self._kind = "plain"
         else:
@@ -81,8 +89,18 @@ class Reader(object):
                 return None
             self._look = look
             return bytes(self._data) + look
-        rd = getattr(self._src, "read1", None) or self._src.read
-        blk = rd(self.BLOCK)
+        if self._kind == "seek":
+            # everything it has, up to the block: the blocks double, so the re-decodes add up to twice the stream
+            blk = bytearray()
+            while len(blk) < self._block:
+                b = self._src.read(self._block - len(blk))
+                if not b:
+                    break
+                blk += b
+            self._block *= 2
+        else:
+            rd = getattr(self._src, "read1", None) or self._src.read
+            blk = rd(self.BLOCK)
         if not blk:
             self._src_eof = True
             return None
@@ -105,7 +123,11 @@ class Reader(object):
         L = capi.lib()
         cap = max(4096, 4 * len(data), 2 * len(self._out))
         while True:
-            out = ctypes.create_string_buffer(cap)
+            if self._outbuf is None or len(self._outbuf) < cap:
+                self._outbuf = ctypes.create_string_buffer(cap)
+            out = self._outbuf
+            cap = len(out)
+            self.decodes += 1
             i, o, e = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
             rc = L.xfg_flate_decode(self._ctx.handle, data, len(data), out, cap,
                                     ctypes.byref(i), ctypes.byref(o), ctypes.byref(e))
@@ -117,7 +139,7 @@ class Reader(object):
                                         "path's single-chunk limit" % capi.MAX_CHUNK_COMP)
             capi.check(rc, "xfg_flate_decode")
             break
-        self._out = out.raw[:o.value]
+        self._out = ctypes.string_at(out, o.value)
         self._final_in = i.value
         self._status = e.value
 

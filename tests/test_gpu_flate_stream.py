@@ -53,8 +53,20 @@ class _OnlyRead(object):
         return self._f.read(n)
 
 
+class _PeekOnly(object):
+    """A buffered source that cannot seek (a pipe behind a bufio.Reader): read and peek, nothing else."""
+    def __init__(self, f):
+        self._f = f
+
+    def read(self, n=-1):
+        return self._f.read(n)
+
+    def peek(self, n=0):
+        return self._f.peek(n)
+
+
 @pytest.mark.parametrize("name", sorted(CORPORA))
-@pytest.mark.parametrize("kind", ["seek", "peek"])
+@pytest.mark.parametrize("kind", ["seek", "peek", "buffered_file"])
 def test_round_trip_canary(ctx, name, kind):
     """flate/flate_test.go:53-96: a canary byte after the final block must not be consumed."""
     from compress_amd import flate
@@ -62,9 +74,13 @@ def test_round_trip_canary(ctx, name, kind):
     comp = zlib.compressobj(6, zlib.DEFLATED, -15)
     stream = comp.compress(data) + comp.flush() + b"\x7a"
     src = io.BytesIO(stream)
+    # (a BufferedReader over a seekable file has peek() AND seek(): it is read ahead and seeked back)
     rd_src = src if kind == "seek" else io.BufferedReader(src, buffer_size=4096)
+    if kind == "peek":
+        rd_src = _PeekOnly(rd_src)
     zr, err = flate.NewReader(rd_src, ctx=ctx)
     assert err is None
+    assert zr._kind == {"seek": "seek", "peek": "peek", "buffered_file": "seek"}[kind]
     got = bytearray()
     from compress_amd import errors
     while True:
@@ -178,3 +194,29 @@ def test_truncated_source(ctx):
         while True:
             got += zr.Read(4096)
     assert len(got) > 0 and data.startswith(bytes(got))
+
+
+def test_large_file_is_decoded_a_bounded_number_of_times(ctx, tmp_path):
+    """A multi-MiB DEFLATE file opened with open(path, "rb") (an io.BufferedReader: peek() and seek()): the Reader has no
+    resume state on the device, so every pull decodes from the stream's start -- the pulls double in size, and the
+    number of xfg_flate_decode calls stays logarithmic (it was one per 8 KiB peek).  The canary after the stream stays unread."""
+    from compress_amd import flate, errors
+    data = _twain() * 8 + os.urandom(4 << 20) + _twain()
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    stream = comp.compress(data) + comp.flush()
+    assert len(stream) > (5 << 20)
+    path = tmp_path / "big.deflate"
+    path.write_bytes(stream + b"\x7a")
+    with open(path, "rb") as f:
+        zr, err = flate.NewReader(f, ctx=ctx)
+        assert err is None and zr._kind == "seek"
+        got = bytearray()
+        while True:
+            try:
+                got += zr.Read(1 << 20)
+            except errors.EOF:
+                break
+        assert bytes(got) == data
+        assert (zr.InputOffset, zr.OutputOffset) == (len(stream), len(data))
+        assert zr.decodes <= 5, zr.decodes                  # 1 + 2 + 4 MiB pulls, and room for an output-buffer retry
+        assert f.read(1) == b"\x7a"

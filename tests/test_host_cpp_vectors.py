@@ -25,7 +25,7 @@ ERRF = {"": capi.ERR_NONE, "IsEOF": capi.ERR_EOF, "IsUnexpectedEOF": capi.ERR_UN
 
 @pytest.fixture(scope="module")
 def L():
-    lib = capi.lib()
+    lib = capi.testhooks_lib()
     vp, sz, i64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64
     pi, psz, pi64 = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz), ctypes.POINTER(i64)
     lib.xfg_test_meta_block.argtypes = [vp, sz, vp, psz, pi, pi64]
@@ -54,8 +54,12 @@ def L():
 
 def test_hooks_header_matches_exports(L):
     header = open(os.path.join(ROOT, "include", "xflate_amd_testhooks.h")).read()
-    for name in set(re.findall(r"\b(xfg_test_[a-z_0-9]+)\s*\(", header)):
+    shipped = capi.lib()
+    names = set(re.findall(r"\b(xfg_test_[a-z_0-9]+)\s*\(", header))
+    assert len(names) >= 10
+    for name in names:
         assert getattr(L, name) is not None
+        assert not hasattr(shipped, name), "%s is exported by the shipped library" % name
 
 
 # ------------------------------------------------------------------ meta
