@@ -715,7 +715,8 @@ __device__ __forceinline__ u32 wave_excl_scan(u32 v, u32 &total);
 
 // ReadPrefixCodes (flate/prefix.go:83-194).  Returns an XFG_ST_* status.
 template <class LDS>
-__device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, int &lit_state, int &dist_state) {
+__device__ __forceinline__ int read_dynamic_header_impl(Reader &r, LDS &L, u32 lane, bool rfc_rep16, int &lit_state, int &dist_state) {
+    HeaderScratch &H = *in_lds(&L.h);                           // (address spaces spelled out: see in_lds)
     refill(r);
     // three ReadBits; each one either gets all its bits or fails consuming none
     if (avail(r) < 5) return XFG_ST_UNEXPECTED_EOF;
@@ -727,7 +728,7 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
     if (hlit > 286 || hdist > 30) return XFG_ST_CORRUPTED;      // prefix.go:87-89
 
     // code-length code lengths, 3 bits each, in clenLens order (prefix.go:67,92-98)
-    if (lane < 19) L.h.clens[lane] = 0;
+    if (lane < 19) H.clens[lane] = 0;
     wave_sync();
     for (u32 i = 0; i < hclen; i++) {
         if (r.bitcnt < 3) refill(r);
@@ -740,11 +741,11 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
         else if (i == 3) s = 0;
         else if ((i & 1) == 0) s = 8 + ((i - 4) >> 1);          // i=4,6,8,..,18 -> 8,9,10,..,15
         else s = 7 - ((i - 5) >> 1);                            // i=5,7,9,..,17 -> 7,6,5,..,1
-        if (lane == 0) L.h.clens[s] = (u8)v;
+        if (lane == 0) H.clens[s] = (u8)v;
     }
     wave_sync();
     int cst;
-    { PROF_T0(); cst = build_table<T_CLEN, CLEN_ROOT, 0>(L, L.h.clen, L.h.clens, 19, lane); PROF_ADD(PF_H_CLEN, lane); }
+    { PROF_T0(); cst = build_table<T_CLEN, CLEN_ROOT, 0>(L, H.clen, H.clens, 19, lane); PROF_ADD(PF_H_CLEN, lane); }
     if (cst == 2) return XFG_ST_CORRUPTED;
     PROF_T0();
 
@@ -752,7 +753,7 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
     // 64 bit positions at a time: lane i looks up the code word that would start at bit hp + i and
     // packs what it means; then a wave-uniform walk hops from symbol to symbol through those
     // answers with readlane (no memory access per symbol).
-    for (u32 i = lane; i < sizeof(L.h.lens) / 4; i += 64) reinterpret_cast<u32 *>(L.h.lens)[i] = 0;
+    for (u32 i = lane; i < sizeof(H.lens) / 4; i += 64) reinterpret_cast<u32 *>(H.lens)[i] = 0;
     // (uni(): the walk below must compile to scalar code, so everything it depends on is pinned to SGPRs)
     const u32 max_syms = uni(hlit + hdist);
     if (cst == 1) return XFG_ST_CORRUPTED;                      // "decode with empty prefix tree"
@@ -769,7 +770,7 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
             const u32 *w32 = reinterpret_cast<const u32 *>(r.win);
             const u32 d0 = w32[(idx >> 2) & (WIN_BYTES / 4 - 1)], d1 = w32[((idx >> 2) + 1) & (WIN_BYTES / 4 - 1)];
             const u32 field = __builtin_amdgcn_alignbyte(d1, d0, idx & 3) >> (qb & 7);    // >= 25 bits; 14 are needed
-            const u32 e = L.h.clen[field & ((1u << CLEN_ROOT) - 1)];
+            const u32 e = H.clen[field & ((1u << CLEN_ROOT) - 1)];
             const u32 take = e_take(e), c = e_val(e) & 31;
             const u32 nb = c == 16 ? 2u : c == 17 ? 3u : c == 18 ? 7u : 0u;
             const u32 xv = (field >> take) & ((1u << nb) - 1);
@@ -797,7 +798,7 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
                 const bool my = (vis >> lane) & 1;
                 u32 total;
                 const u32 idx = sym + wave_excl_scan(my ? cnt : 0u, total);
-                if (my && c < 16 && idx < max_syms) L.h.lens[idx] = (u8)c;
+                if (my && c < 16 && idx < max_syms) H.lens[idx] = (u8)c;
                 const u64 m16 = __ballot(my && c == 16);
                 const u64 mexp = __ballot(my && c < 16);             // explicit lengths
                 if (m16) {
@@ -807,12 +808,12 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
                         const u32 il = (u32)__builtin_amdgcn_readlane((int)idx, (int)l);
                         const u32 rp = (u32)__builtin_amdgcn_readlane((int)cnt, (int)l);
                         u32 v;
-                        if (rfc_rep16) v = uni(L.h.lens[il - 1]);    // the previous array entry (il >= 1: sym > 0)
+                        if (rfc_rep16) v = uni(H.lens[il - 1]);    // the previous array entry (il >= 1: sym > 0)
                         else {
                             const u64 before = mexp & ((1ull << l) - 1);
                             v = before ? (u32)__builtin_amdgcn_readlane((int)c, 63 - __builtin_clzll(before)) : prev;
                         }
-                        if (lane < rp && il + lane < max_syms) L.h.lens[il + lane] = (u8)v;
+                        if (lane < rp && il + lane < max_syms) H.lens[il + lane] = (u8)v;
                         wave_sync();
                     }
                 }
@@ -824,7 +825,7 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
         if (!fast) {
             // Exact way, symbol by symbol: every read of the reference that can fail is checked where it fails.
             wave_sync();
-            if (rfc_rep16 && sym > 0) prev = uni(L.h.lens[sym - 1]);
+            if (rfc_rep16 && sym > 0) prev = uni(H.lens[sym - 1]);
             while (pos < 64 && sym < max_syms) {
                 const u32 inf = (u32)__builtin_amdgcn_readlane((int)info, (int)pos);
                 const i32 av = (i32)total_bits - (i32)(hp + pos);
@@ -834,7 +835,7 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
                 if (inf >> 31) { st = XFG_ST_CORRUPTED; break; }      // the degenerate filler symbol
                 const u32 c = (inf >> 8) & 31;
                 if (c < 16) {
-                    if (lane == 0) L.h.lens[sym] = (u8)c;
+                    if (lane == 0) H.lens[sym] = (u8)c;
                     prev = c;
                     sym++;
                     continue;
@@ -847,7 +848,7 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
                 const u32 rep = (c == 18 ? 11u : 3u) + ((inf >> 16) & 127);
                 if (c != 16 && rfc_rep16) prev = 0;                 // stdlib: 16 repeats the previous array entry
                 const u32 end = sym + rep;
-                for (u32 k = sym + lane; k < end && k < max_syms; k += 64) L.h.lens[k] = (u8)val;
+                for (u32 k = sym + lane; k < end && k < max_syms; k += 64) H.lens[k] = (u8)val;
                 sym = end;
                 if (sym > max_syms) { st = XFG_ST_CORRUPTED; break; } // prefix.go:161-163
             }
@@ -859,23 +860,39 @@ __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, 
     wave_sync();
     PROF_ADD(PF_H_LENS, lane);
     // lens[0 .. hlit) literal/length, lens[hlit .. hlit+hdist) distance
-    { PROF_T0(); lit_state = build_table<T_LIT, LIT_ROOT, 0>(L, L.tab, L.h.lens, hlit, lane); PROF_ADD(PF_H_LIT, lane); }
+    { PROF_T0(); lit_state = build_table<T_LIT, LIT_ROOT, 0>(L, L.tab, H.lens, hlit, lane); PROF_ADD(PF_H_LIT, lane); }
     if (lit_state == 2) return XFG_ST_CORRUPTED;
-    { PROF_T0(); dist_state = build_table<T_DIST, DIST_ROOT, LIT_TAB>(L, (L.tab + LIT_TAB), L.h.lens + hlit, hdist, lane); PROF_ADD(PF_H_DIST, lane); }
+    { PROF_T0(); dist_state = build_table<T_DIST, DIST_ROOT, LIT_TAB>(L, (L.tab + LIT_TAB), H.lens + hlit, hdist, lane); PROF_ADD(PF_H_DIST, lane); }
     if (dist_state == 2) return XFG_ST_CORRUPTED;
     return XFG_ST_OK;
+}
+
+// (The reader's pointers with their address spaces spelled out, for when this is not inlined: see in_lds.)
+__device__ __forceinline__ Reader reader_known(const Reader &r) {
+    Reader k = r;
+    k.comp = in_global(r.comp);
+    k.win = in_lds(r.win);
+    return k;
+}
+template <class LDS>
+__device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, int &lit_state, int &dist_state) {
+    Reader k = reader_known(r);
+    const int st = read_dynamic_header_impl(k, L, lane, rfc_rep16, lit_state, dist_state);
+    r = k;
+    return st;
 }
 
 // Fixed code sets of RFC 1951 3.2.6 (flate/prefix.go:35-63).
 template <class LDS>
 __device__ void build_fixed(LDS &L, u32 lane) {
+    HeaderScratch &H = *in_lds(&L.h);
     for (u32 i = lane; i < 288; i += 64)
-        L.h.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+        H.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
     wave_sync();
-    build_table<T_LIT, LIT_ROOT, 0>(L, L.tab, L.h.lens, 288, lane);
-    if (lane < 32) L.h.clens[lane] = 5;
+    build_table<T_LIT, LIT_ROOT, 0>(L, L.tab, H.lens, 288, lane);
+    if (lane < 32) H.clens[lane] = 5;
     wave_sync();
-    build_table<T_DIST, DIST_ROOT, LIT_TAB>(L, (L.tab + LIT_TAB), L.h.clens, 32, lane);
+    build_table<T_DIST, DIST_ROOT, LIT_TAB>(L, (L.tab + LIT_TAB), H.clens, 32, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1699,6 +1716,9 @@ __device__ __forceinline__ u32 seg_bits_for(u32 out_bytes, u32 in_bits) {
 #ifndef XFG_WG_KEEP_SHORT
 #define XFG_WG_KEEP_SHORT 1             // match-heavy batches (short segments) stay with wave 0 as well: repeats kind 65 -> 77 GB/s at 768 chunks
 #endif
+#ifndef XFG_WG_SERIAL
+#define XFG_WG_SERIAL 1                 // serial batches are shared out over the workgroup's waves (wg_serial_group)
+#endif
 constexpr int XFG_ST_AGAIN = -100;                              // never leaves the kernel
 // Segments of XFG_SEG_RUN bits follow a batch whose output was nearly all long matches or runs (seg_bits_for).
 __device__ __forceinline__ bool wg_keeps(u32 seg_bits) {
@@ -1708,7 +1728,7 @@ __device__ __forceinline__ bool wg_keeps(u32 seg_bits) {
 template <bool WG = false, class LDS>
 __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 lane, u32 p0,
                                          int lit_state, int dist_state, u32 spec_back, u32 max_fix, u32 &seg_bits,
-                                         bool serial_init = false)
+                                         bool serial_init = false, bool *serial_out = nullptr)
 {
     BlockEnd be;
     if (lit_state == 1) { be.status = XFG_ST_CORRUPTED; be.bitpos = p0; return be; }   // empty literal tree
@@ -1722,7 +1742,11 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
     for (u32 nbatch = 0;; nbatch++) {
         if (nbatch > total_bits + 4) { be.status = XFG_ST_INTERNAL; be.bitpos = p0; return be; }   // every batch consumes >= 1 bit
         // (batches of runs and long matches stay with wave 0: their write-out is all there is to them, and a group's write-outs are serial)
-        if (WG && nbatch > 0 && !dist_empty && !force_tail && !serial && p0 + 64u <= total_bits && !wg_keeps(seg_bits)) { be.status = XFG_ST_AGAIN; be.bitpos = p0; return be; }
+        // (and serial batches go back to the workgroup, whose waves take them in turns: wg_serial_group)
+        if (WG && nbatch > 0 && !dist_empty && !force_tail && p0 + 64u <= total_bits && (serial ? XFG_WG_SERIAL != 0 : !wg_keeps(seg_bits))) {
+            if (serial_out) *serial_out = serial;
+            be.status = XFG_ST_AGAIN; be.bitpos = p0; return be;
+        }
         // ---- compressed window of this batch (fetched during the previous batch's stage 2 when there was one)
         const i32 wb0 = (i32)(((stream0 + (p0 >> 3)) & ~(i64)15) - stream0);
         {
