@@ -272,6 +272,7 @@ struct alignas(16) WaveLds {
 #endif
     // bytes from the start of win that a round's token list and output window share, and where the bytes go that
     // nobody reads (DUMP_POS below); the workgroup kernel's waves may have more room (inflate_wg_kernel.inc)
+    static constexpr bool pointers_known = true;               // a __shared__ object of the kernel itself: the compiler sees what every access is
     static constexpr u32 room_total = WT_BYTES + OUT_LDS;
     static constexpr u32 dump = WT_BYTES + OUT_LDS + 16;
 };
@@ -876,6 +877,7 @@ __device__ __forceinline__ Reader reader_known(const Reader &r) {
 }
 template <class LDS>
 __device__ int read_dynamic_header(Reader &r, LDS &L, u32 lane, bool rfc_rep16, int &lit_state, int &dist_state) {
+    if (LDS::pointers_known) return read_dynamic_header_impl(r, L, lane, rfc_rep16, lit_state, dist_state);   // (the one-wave kernel: everything is inlined)
     Reader k = reader_known(r);
     const int st = read_dynamic_header_impl(k, L, lane, rfc_rep16, lit_state, dist_state);
     r = k;
