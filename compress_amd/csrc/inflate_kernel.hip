@@ -483,6 +483,8 @@ __device__ __forceinline__ u32 reader_bitpos(const Reader &r) { return r.bytepos
 // Returns 0 = ok, 1 = empty code (decode with it is an error), 2 = invalid
 // (over/under-subscribed: GeneratePrefixes errors, prefix.go:355-369).
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 wave_incl_scan(u32 v);
+
 template <int TYPE, int ROOT, int TAB_OFF, class LDS>
 __device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane) {
     struct View { HeaderScratch &h; u32 *tab;
@@ -497,24 +499,46 @@ __device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane)
     };
     u32 *tab = in_lds(tab_);
     const u8 *lens = in_lds(lens_);
-    // 1. histogram of code lengths
 #ifdef XFG_PROFILE
     const unsigned long long bt0_ = __builtin_amdgcn_s_memtime();
 #endif
-    if (lane < 16) L.h.cnt[lane] = 0;
-    wave_sync();
-    for (u32 i = lane; i < n; i += 64) {
-        const u32 l = lens[i];
-        if (l) atomicAdd(&L.h.cnt[l], 1u);
+    // 1. How many codes of each length, and every symbol's rank among the symbols of its length, in one sweep: a lane
+    //    holds symbols lane, 64 + lane, ...; length q (1..15) is a 10-bit field ((q - 1) % 3) of packed word (q - 1) / 3
+    //    (there are <= 320 symbols), a symbol is a one in its length's field, and an inclusive prefix sum over the
+    //    wave (DPP, no LDS), carried from one 64-symbol piece to the next, counts the symbols of that length up to and
+    //    including this one.  After the last piece the carry is the histogram.
+    constexpr int NK = TYPE == T_LIT ? 5 : 1;                   // 64-symbol pieces: n <= 320 literal/length, <= 32 distance, 19 code-length symbols
+    constexpr int QMAX = TYPE == T_CLEN ? 7 : 15;               // the code-length code's lengths are 3-bit values
+    constexpr int NW = (QMAX - 1) / 3 + 1;
+    u32 lk[NK], rk[NK];
+    u32 carry[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) carry[w] = 0;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const u32 i = (u32)k * 64u + lane;
+        const u32 l = i < n ? (u32)lens[i] : 0u;
+        lk[k] = l;
+        const u32 t = l ? l - 1 : 0u;                           // (l = 0: no field)
+        const u32 wsel = (t * 11u) >> 5;                        // t / 3 for t < 15
+        const u32 sh = 10u * (t - 3u * wsel);
+        const u32 f = l ? 1u << sh : 0u;
+        u32 own = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const u32 incl = wave_incl_scan(wsel == (u32)w ? f : 0u) + carry[w];
+            carry[w] = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            own = wsel == (u32)w ? incl : own;
+        }
+        rk[k] = ((own >> sh) & 1023u) - 1u;
     }
-    wave_sync();
 
     // 2. Kraft check and canonical first codes (uniform; every lane computes the same)
     u32 cnt[16];
     u32 nz = 0, maxlen = 0;
 #pragma unroll
     for (int l = 1; l <= 15; l++) {
-        cnt[l] = uni(L.h.cnt[l]);
+        cnt[l] = l <= QMAX ? (carry[(l - 1) / 3] >> (10 * ((l - 1) % 3))) & 1023u : 0u;
         nz += cnt[l];
         if (cnt[l]) maxlen = l;
     }
@@ -536,36 +560,35 @@ __device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane)
         }
         if (left != 0) return 2;
     }
-    u32 run[16];
+    // first[l]: first canonical code of length l; offs[l]: index in sorted[] of its symbol; endr[l]: end of the
+    // length-l codes in ROOT-bit code space (l <= ROOT).  All wave-uniform (scalar registers); what the lanes look up
+    // by a length of their own goes to LDS, lane l writing entry l: offs[], base[] = offs - first (the symbol of code c
+    // of length l is sorted[base[l] + c]) and lim[] = first + cnt.
+    u32 first[16], offs[16], endr[ROOT + 1];
     {
         u32 code = 0, off = 0;
+        u32 v_offs = 0, v_base = 0, v_lim = 0;
 #pragma unroll
         for (int l = 1; l <= 15; l++) {
             code <<= 1;
-            run[l] = off;
-
-            if (lane == 0) {
-                L.h.first[l] = code;
-                L.h.offs[l] = off;
-                L.h.cnt[l] = cnt[l];
-                if (l <= ROOT) L.h.endr[l] = (code + cnt[l]) << (ROOT - l);
-            }
+            first[l] = code;
+            offs[l] = off;
+            if (l <= ROOT) endr[l] = (code + cnt[l]) << (ROOT - l);
+            v_offs = lane == (u32)l ? off : v_offs;
+            v_base = lane == (u32)l ? off - code : v_base;
+            v_lim = lane == (u32)l ? code + cnt[l] : v_lim;
             code += cnt[l];
             off += cnt[l];
         }
+        if (lane < 16) { L.h.offs[lane] = v_offs; L.h.first[lane] = v_base; L.h.cnt[lane] = v_lim; }
     }
+    wave_sync();
 
     // 3. canonical order: sorted[offs[len] + rank within len] = symbol
-    for (u32 base = 0; base < n; base += 64) {
-        const u32 i = base + lane;
-        const u32 l = (i < n) ? lens[i] : 0;
 #pragma unroll
-        for (int q = 1; q <= 15; q++) {
-            if (cnt[q] == 0) continue;
-            const u64 m = __ballot(l == (u32)q);
-            if (l == (u32)q) L.h.sorted[run[q] + __popcll(m & ((1ull << lane) - 1))] = (u16)i;
-            run[q] += __popcll(m);
-        }
+    for (int k = 0; k < NK; k++) {
+        const u32 l = lk[k];
+        if (l) L.h.sorted[L.h.offs[l] + rk[k]] = (u16)((u32)k * 64u + lane);
     }
     if (degenerate && lane == 0) L.h.sorted[1] = 0xffff;          // the out-of-range sibling
     wave_sync();
@@ -575,14 +598,17 @@ __device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane)
 #endif
 
     // 4. root table.  u runs over ROOT-bit code space MSB-first; the table is indexed LSB-first.
-    //    Codes of length l <= ROOT own [endr[l-1], endr[l]) there; whatever lies at or beyond
-    //    end_root is the prefix of a longer code.
-    const u32 lim = maxlen < (u32)ROOT ? maxlen : (u32)ROOT;
-    const u32 end_root = uni(L.h.endr[lim]);
+    //    Codes of length l <= ROOT own [endr[l-1], endr[l]) there (endr is non-decreasing: the length is one more than
+    //    the number of ends at or below u); whatever lies at or beyond end_root is the prefix of a longer code.
+    u32 end_root = 0;
+#pragma unroll
+    for (int l = 1; l <= ROOT; l++)
+        if ((u32)l == (maxlen < (u32)ROOT ? maxlen : (u32)ROOT)) end_root = endr[l];
     for (u32 u = lane; u < end_root; u += 64) {
         u32 l = 1;
-        while (l < (u32)ROOT && u >= L.h.endr[l]) l++;
-        const u32 sym = L.h.sorted[L.h.offs[l] + (u >> (ROOT - l)) - L.h.first[l]];
+#pragma unroll
+        for (int q = 1; q < ROOT; q++) l += u >= endr[q] ? 1u : 0u;
+        const u32 sym = L.h.sorted[L.h.first[l] + (u >> (ROOT - l))];
         tab[__brev(u) >> (32 - ROOT)] = sym_entry(TYPE, sym, l);
     }
 
@@ -592,39 +618,37 @@ __device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane)
 #endif
     // 5. sub-tables for code words longer than ROOT: one per ROOT-bit prefix u >= end_root,
     //    sized by the longest code under that prefix (as zlib's inftrees does).
-    if (maxlen > (u32)ROOT) {
+    if (TYPE != T_CLEN && maxlen > (u32)ROOT) {
         u32 next = 1u << ROOT;                                  // running sub-table offset (uniform)
         const u32 tab_lds = (u32)(uintptr_t)(const __attribute__((address_space(3))) u32 *)L.tab;
         for (u32 ub = end_root; ub < (1u << ROOT); ub += 64) {
             const u32 u = ub + lane;
             const bool act = u < (1u << ROOT);
             u32 sb = 0;
-            if (act) {
-                for (u32 l = maxlen; l > (u32)ROOT; l--) {
-                    const u32 c = L.h.cnt[l];
-                    if (!c) continue;
-                    const u32 f = L.h.first[l];
-                    const u32 lo = u << (l - ROOT), hi = (u + 1) << (l - ROOT);
-                    if (lo < f + c && hi > f) { sb = l - ROOT; break; }
-                }
+#pragma unroll
+            for (int l = ROOT + 1; l <= 15; l++) {              // the longest length with a code under this prefix
+                const u32 lo = u << (l - ROOT), hi = (u + 1) << (l - ROOT);
+                if (cnt[l] && lo < first[l] + cnt[l] && hi > first[l]) sb = (u32)(l - ROOT);
             }
+            if (!act) sb = 0;
             // exclusive scan of sub-table sizes over the wave
             const u32 size = act ? (1u << sb) : 0;
-            u32 incl = size;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const u32 t = __shfl_up(incl, d);
-                if (lane >= (u32)d) incl += t;
-            }
+            const u32 incl = wave_incl_scan(size);
             const u32 my_off = next + incl - size;
-            next += uni(__shfl(incl, 63));
+            next += (u32)__builtin_amdgcn_readlane((int)incl, 63);
             if (act) {
                 tab[__brev(u) >> (32 - ROOT)] = mk_entry(ROOT, K_SUB, sb, tab_lds + 4 * (my_off + TAB_OFF));   // LDS address of the sub-table
                 for (u32 v = 0; v < (1u << sb); v++) {
                     const u32 w = (u << sb) | v;                // (ROOT+sb)-bit code space, MSB-first
+                    // the first length whose codes end above w's prefix of that length
                     u32 l = ROOT + 1;
-                    while (l < ROOT + sb && (w >> (ROOT + sb - l)) >= L.h.first[l] + L.h.cnt[l]) l++;
-                    const u32 sym = L.h.sorted[L.h.offs[l] + (w >> (ROOT + sb - l)) - L.h.first[l]];
+                    bool on = true;
+#pragma unroll
+                    for (int q = ROOT + 1; q < 15; q++) {
+                        on = on && (u32)q < ROOT + sb && (w >> (ROOT + sb - q)) >= first[q] + cnt[q];
+                        l += on ? 1u : 0u;
+                    }
+                    const u32 sym = L.h.sorted[L.h.first[l] + (w >> (ROOT + sb - l))];
                     tab[my_off + (__brev(v) >> (32 - sb))] = sym_entry(TYPE, sym, l - ROOT);  // the link consumed ROOT bits
                 }
             }
@@ -731,23 +755,45 @@ __device__ __forceinline__ int read_dynamic_header_impl(Reader &r, LDS &L, u32 l
     // code-length code lengths, 3 bits each, in clenLens order (prefix.go:67,92-98)
     if (lane < 19) H.clens[lane] = 0;
     wave_sync();
-    for (u32 i = 0; i < hclen; i++) {
-        if (r.bitcnt < 3) refill(r);
-        if (avail(r) < 3) return XFG_ST_UNEXPECTED_EOF;
-        const u32 v = peek(r, 3);
-        consume(r, 3);
+    bool clens_vec = false;                                     // (then r still stands before the 3-bit fields; hp_after is where they end)
+    const u32 hp_clens = uni(reader_bitpos(r));
+    const u32 hp_after = hp_clens + 3u * uni(hclen);
+    if (hp_clens + 3u * 19u + 64u <= r.total * 8u) {
+        // every field is there: lane i reads field i straight from the window
+        clens_vec = true;
+        win_ensure_at(r, hp_clens >> 3, 16);
+        const u32 qb = hp_clens + 3u * lane;
+        const u32 idx = (qb >> 3) + r.lead;
+        const u32 *w32 = reinterpret_cast<const u32 *>(r.win);
+        const u32 d0 = w32[(idx >> 2) & (WIN_BYTES / 4 - 1)], d1 = w32[((idx >> 2) + 1) & (WIN_BYTES / 4 - 1)];
+        const u32 v = (__builtin_amdgcn_alignbyte(d1, d0, idx & 3) >> (qb & 7)) & 7u;
         // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
-        u32 s;
-        if (i < 3) s = 16 + i;
-        else if (i == 3) s = 0;
-        else if ((i & 1) == 0) s = 8 + ((i - 4) >> 1);          // i=4,6,8,..,18 -> 8,9,10,..,15
-        else s = 7 - ((i - 5) >> 1);                            // i=5,7,9,..,17 -> 7,6,5,..,1
-        if (lane == 0) H.clens[s] = (u8)v;
+        const u32 i = lane;
+        u32 sidx;
+        if (i < 3) sidx = 16 + i;
+        else if (i == 3) sidx = 0;
+        else if ((i & 1) == 0) sidx = 8 + ((i - 4) >> 1);
+        else sidx = 7 - ((i - 5) >> 1);
+        if (i < hclen) H.clens[sidx] = (u8)v;
+    } else {
+        for (u32 i = 0; i < hclen; i++) {
+            if (r.bitcnt < 3) refill(r);
+            if (avail(r) < 3) return XFG_ST_UNEXPECTED_EOF;
+            const u32 v = peek(r, 3);
+            consume(r, 3);
+            // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
+            u32 s;
+            if (i < 3) s = 16 + i;
+            else if (i == 3) s = 0;
+            else if ((i & 1) == 0) s = 8 + ((i - 4) >> 1);          // i=4,6,8,..,18 -> 8,9,10,..,15
+            else s = 7 - ((i - 5) >> 1);                            // i=5,7,9,..,17 -> 7,6,5,..,1
+            if (lane == 0) H.clens[s] = (u8)v;
+        }
     }
     wave_sync();
     int cst;
     { PROF_T0(); cst = build_table<T_CLEN, CLEN_ROOT, 0>(L, H.clen, H.clens, 19, lane); PROF_ADD(PF_H_CLEN, lane); }
-    if (cst == 2) return XFG_ST_CORRUPTED;
+    if (cst == 2) { if (clens_vec) reader_seek(r, hp_after); return XFG_ST_CORRUPTED; }
     PROF_T0();
 
     // literal/length and distance code lengths with the 16/17/18 repeaters (prefix.go:125-165).
@@ -757,9 +803,9 @@ __device__ __forceinline__ int read_dynamic_header_impl(Reader &r, LDS &L, u32 l
     for (u32 i = lane; i < sizeof(H.lens) / 4; i += 64) reinterpret_cast<u32 *>(H.lens)[i] = 0;
     // (uni(): the walk below must compile to scalar code, so everything it depends on is pinned to SGPRs)
     const u32 max_syms = uni(hlit + hdist);
-    if (cst == 1) return XFG_ST_CORRUPTED;                      // "decode with empty prefix tree"
+    if (cst == 1) { if (clens_vec) reader_seek(r, hp_after); return XFG_ST_CORRUPTED; }   // "decode with empty prefix tree"
     const u32 total_bits = uni(r.total * 8);
-    u32 hp = uni(reader_bitpos(r));
+    u32 hp = clens_vec ? hp_after : uni(reader_bitpos(r));
     u32 prev = 0;                                               // clenLast
     int st = XFG_ST_OK;
     for (u32 sym = 0; sym < max_syms && st == XFG_ST_OK;) {
@@ -781,7 +827,7 @@ __device__ __forceinline__ int read_dynamic_header_impl(Reader &r, LDS &L, u32 l
         // Fast way: every symbol of the window is whole (no end of input near) -- hop through the window
         // keeping only positions and counts, then let the lanes that were hopped on store their lengths
         // at once.  Zero runs need no store (lens[] was cleared); "repeat previous" runs follow in order.
-        bool fast = hp + 64 + 16 <= total_bits && sym > 0;
+        bool fast = hp + 64 + 16 <= total_bits;
         if (fast) {
             const u32 c = (info >> 8) & 31;
             const u32 cnt = c < 16 ? 1u : (c == 18 ? 11u : 3u) + ((info >> 16) & 127);
@@ -794,7 +840,8 @@ __device__ __forceinline__ int read_dynamic_header_impl(Reader &r, LDS &L, u32 l
                 pos += i2 & 31;
                 s2 += i2 >> 8;
             }
-            if (__ballot((info >> 31) != 0) & vis) { fast = false; pos = 0; }    // an invalid code on the path: the exact way
+            // an invalid code on the path, or a repeat with nothing before it (prefix.go:139-141): the exact way
+            if ((__ballot((info >> 31) != 0) & vis) || (sym == 0 && ((u32)__builtin_amdgcn_readlane((int)c, 0)) == 16)) { fast = false; pos = 0; }
             else {
                 const bool my = (vis >> lane) & 1;
                 u32 total;
@@ -802,23 +849,30 @@ __device__ __forceinline__ int read_dynamic_header_impl(Reader &r, LDS &L, u32 l
                 if (my && c < 16 && idx < max_syms) H.lens[idx] = (u8)c;
                 const u64 m16 = __ballot(my && c == 16);
                 const u64 mexp = __ballot(my && c < 16);             // explicit lengths
+                u32 v16 = 0;
                 if (m16) {
-                    wave_sync();
-                    for (u64 m = m16; m; m &= m - 1) {
-                        const u32 l = (u32)__ffsll((long long)m) - 1;
-                        const u32 il = (u32)__builtin_amdgcn_readlane((int)idx, (int)l);
-                        const u32 rp = (u32)__builtin_amdgcn_readlane((int)cnt, (int)l);
-                        u32 v;
-                        if (rfc_rep16) v = uni(H.lens[il - 1]);    // the previous array entry (il >= 1: sym > 0)
-                        else {
-                            const u64 before = mexp & ((1ull << l) - 1);
-                            v = before ? (u32)__builtin_amdgcn_readlane((int)c, 63 - __builtin_clzll(before)) : prev;
-                        }
-                        if (lane < rp && il + lane < max_syms) H.lens[il + lane] = (u8)v;
-                        wave_sync();
+                    // What a "repeat previous" run repeats comes from the nearest lane below it on the path that is not
+                    // such a run itself: the previous array entry (an explicit length, or zero after a zero run), or in
+                    // the in-repo reader's reading the last explicit length (clenLast); from before this window if there
+                    // is no such lane.  Every run's lane stores its own 3 to 6 entries.
+                    const u64 msrc = rfc_rep16 ? __ballot(my && c != 16) : mexp;
+                    const u64 below = msrc & ((1ull << lane) - 1);
+                    const u32 j = below ? 63u - (u32)__builtin_clzll(below) : 0u;
+                    const u32 got = (u32)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)(c < 16 ? c : 0u));
+                    v16 = below ? got : prev;
+                    if (my && c == 16) {
+#pragma unroll
+                        for (u32 t = 0; t < 6; t++)
+                            if (t < cnt && idx + t < max_syms) H.lens[idx + t] = (u8)v16;
                     }
                 }
-                if (mexp) prev = (u32)__builtin_amdgcn_readlane((int)c, 63 - __builtin_clzll(mexp));
+                if (rfc_rep16) {
+                    // the last array entry written: what the last lane on the path stands for
+                    const u32 jl = 63u - (u32)__builtin_clzll(vis);
+                    prev = (u32)__builtin_amdgcn_readlane((int)(c < 16 ? c : c == 16 ? v16 : 0u), (int)jl);
+                } else if (mexp) {
+                    prev = (u32)__builtin_amdgcn_readlane((int)c, 63 - __builtin_clzll(mexp));
+                }
                 sym = s2;
                 if (sym > max_syms) st = XFG_ST_CORRUPTED;          // prefix.go:161-163
             }
