@@ -311,6 +311,9 @@ __device__ __forceinline__ TokList token_list(LDS &L, u32 seg_bits) {
     return t;
 }
 
+#ifndef XFG_PROF_TABLE
+#define XFG_PROF_TABLE T_LIT            // which table's build the t_sort / t_root / t_sub timers follow (diagnostic build)
+#endif
 #ifdef XFG_PROFILE
 // Accumulated per wave in LDS (WaveLds::prof) and added to the global array once per chunk,
 // so that the instrumentation puts no memory traffic into the phases it times.
@@ -486,7 +489,7 @@ __device__ __forceinline__ u32 reader_bitpos(const Reader &r) { return r.bytepos
 __device__ __forceinline__ u32 wave_incl_scan(u32 v);
 
 template <int TYPE, int ROOT, int TAB_OFF, class LDS>
-__device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane) {
+__device__ __attribute__((noinline)) int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane) {
     struct View { HeaderScratch &h; u32 *tab;
 #ifdef XFG_PROFILE
                   unsigned long long *prof;
@@ -560,67 +563,37 @@ __device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane)
         }
         if (left != 0) return 2;
     }
-    // first[l]: first canonical code of length l; offs[l]: index in sorted[] of its symbol; endr[l]: end of the
-    // length-l codes in ROOT-bit code space (l <= ROOT).  All wave-uniform (scalar registers); what the lanes look up
-    // by a length of their own goes to LDS, lane l writing entry l: offs[], base[] = offs - first (the symbol of code c
-    // of length l is sorted[base[l] + c]) and lim[] = first + cnt.
-    u32 first[16], offs[16], endr[ROOT + 1];
+    // first[l]: first canonical code of length l; endr[l]: end of the length-l codes in ROOT-bit code space
+    // (l <= ROOT).  All wave-uniform (scalar registers); lane l puts first[l] into LDS for the lanes to look up by
+    // a length of their own.
+    u32 first[16], endr[ROOT + 1];
     {
-        u32 code = 0, off = 0;
-        u32 v_offs = 0, v_base = 0, v_lim = 0;
+        u32 code = 0;
+        u32 v_first = 0;
 #pragma unroll
         for (int l = 1; l <= 15; l++) {
             code <<= 1;
             first[l] = code;
-            offs[l] = off;
             if (l <= ROOT) endr[l] = (code + cnt[l]) << (ROOT - l);
-            v_offs = lane == (u32)l ? off : v_offs;
-            v_base = lane == (u32)l ? off - code : v_base;
-            v_lim = lane == (u32)l ? code + cnt[l] : v_lim;
+            v_first = lane == (u32)l ? code : v_first;
             code += cnt[l];
-            off += cnt[l];
         }
-        if (lane < 16) { L.h.offs[lane] = v_offs; L.h.first[lane] = v_base; L.h.cnt[lane] = v_lim; }
+        if (lane < 16) L.h.first[lane] = v_first;
     }
-    wave_sync();
-
-    // 3. canonical order: sorted[offs[len] + rank within len] = symbol
-#pragma unroll
-    for (int k = 0; k < NK; k++) {
-        const u32 l = lk[k];
-        if (l) L.h.sorted[L.h.offs[l] + rk[k]] = (u16)((u32)k * 64u + lane);
-    }
-    if (degenerate && lane == 0) L.h.sorted[1] = 0xffff;          // the out-of-range sibling
-    wave_sync();
-#ifdef XFG_PROFILE
-    const unsigned long long bt1_ = __builtin_amdgcn_s_memtime();
-    if (TYPE == T_LIT && lane == 0) L.prof[PF_T_SORT] += bt1_ - bt0_;
-#endif
-
-    // 4. root table.  u runs over ROOT-bit code space MSB-first; the table is indexed LSB-first.
-    //    Codes of length l <= ROOT own [endr[l-1], endr[l]) there (endr is non-decreasing: the length is one more than
-    //    the number of ends at or below u); whatever lies at or beyond end_root is the prefix of a longer code.
-    u32 end_root = 0;
+    u32 end_root = 0;                                           // ROOT-bit prefixes at or beyond it belong to longer codes
 #pragma unroll
     for (int l = 1; l <= ROOT; l++)
         if ((u32)l == (maxlen < (u32)ROOT ? maxlen : (u32)ROOT)) end_root = endr[l];
-    for (u32 u = lane; u < end_root; u += 64) {
-        u32 l = 1;
-#pragma unroll
-        for (int q = 1; q < ROOT; q++) l += u >= endr[q] ? 1u : 0u;
-        const u32 sym = L.h.sorted[L.h.first[l] + (u >> (ROOT - l))];
-        tab[__brev(u) >> (32 - ROOT)] = sym_entry(TYPE, sym, l);
-    }
-
 #ifdef XFG_PROFILE
-    const unsigned long long bt2_ = __builtin_amdgcn_s_memtime();
-    if (TYPE == T_LIT && lane == 0) L.prof[PF_T_ROOT] += bt2_ - bt1_;
+    const unsigned long long bt1_ = __builtin_amdgcn_s_memtime();
+    if (TYPE == XFG_PROF_TABLE && lane == 0) L.prof[PF_T_SORT] += bt1_ - bt0_;
 #endif
-    // 5. sub-tables for code words longer than ROOT: one per ROOT-bit prefix u >= end_root,
-    //    sized by the longest code under that prefix (as zlib's inftrees does).
+
+    // 3. links: one second-level table per ROOT-bit prefix u >= end_root, sized by the longest code under that
+    //    prefix (as zlib's inftrees does); the root entry of the prefix says where it is and how many bits index it.
+    const u32 tab_lds = (u32)(uintptr_t)(const __attribute__((address_space(3))) u32 *)L.tab;
     if (TYPE != T_CLEN && maxlen > (u32)ROOT) {
         u32 next = 1u << ROOT;                                  // running sub-table offset (uniform)
-        const u32 tab_lds = (u32)(uintptr_t)(const __attribute__((address_space(3))) u32 *)L.tab;
         for (u32 ub = end_root; ub < (1u << ROOT); ub += 64) {
             const u32 u = ub + lane;
             const bool act = u < (1u << ROOT);
@@ -631,32 +604,63 @@ __device__ int build_table(LDS &L_, u32 *tab_, const u8 *lens_, u32 n, u32 lane)
                 if (cnt[l] && lo < first[l] + cnt[l] && hi > first[l]) sb = (u32)(l - ROOT);
             }
             if (!act) sb = 0;
-            // exclusive scan of sub-table sizes over the wave
             const u32 size = act ? (1u << sb) : 0;
             const u32 incl = wave_incl_scan(size);
             const u32 my_off = next + incl - size;
             next += (u32)__builtin_amdgcn_readlane((int)incl, 63);
-            if (act) {
-                tab[__brev(u) >> (32 - ROOT)] = mk_entry(ROOT, K_SUB, sb, tab_lds + 4 * (my_off + TAB_OFF));   // LDS address of the sub-table
-                for (u32 v = 0; v < (1u << sb); v++) {
-                    const u32 w = (u << sb) | v;                // (ROOT+sb)-bit code space, MSB-first
-                    // the first length whose codes end above w's prefix of that length
-                    u32 l = ROOT + 1;
-                    bool on = true;
-#pragma unroll
-                    for (int q = ROOT + 1; q < 15; q++) {
-                        on = on && (u32)q < ROOT + sb && (w >> (ROOT + sb - q)) >= first[q] + cnt[q];
-                        l += on ? 1u : 0u;
-                    }
-                    const u32 sym = L.h.sorted[L.h.first[l] + (w >> (ROOT + sb - l))];
-                    tab[my_off + (__brev(v) >> (32 - sb))] = sym_entry(TYPE, sym, l - ROOT);  // the link consumed ROOT bits
-                }
-            }
+            if (act) tab[__brev(u) >> (32 - ROOT)] = mk_entry(ROOT, K_SUB, sb, tab_lds + 4 * (my_off + TAB_OFF));   // LDS address of the sub-table
         }
     }
     wave_sync();
 #ifdef XFG_PROFILE
-    if (TYPE == T_LIT && lane == 0) L.prof[PF_T_SUB] += __builtin_amdgcn_s_memtime() - bt2_;
+    const unsigned long long bt2_ = __builtin_amdgcn_s_memtime();
+    if (TYPE == XFG_PROF_TABLE && lane == 0) L.prof[PF_T_ROOT] += bt2_ - bt1_;
+#endif
+
+    // 4. every symbol writes its own entries.  Its code word is first[len] + its rank among the symbols of its length
+    //    (the canonical order); the tables are indexed LSB-first.  A code of l <= ROOT bits owns the 2^(ROOT - l) root
+    //    entries whose low l bits are the reversed code; a longer one the entries of its prefix's second-level table
+    //    whose low l - ROOT bits are the rest of the code, reversed.
+    u32 fl[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) fl[k] = L.h.first[lk[k]];
+    //    Short codes have many entries (2^(ROOT - l)): those are written by the whole wave, one code after the other.
+    constexpr u32 OWN_MIN = ROOT >= 3 ? ROOT - 2 : 1;           // codes of at least this many bits (<= 4 entries) are written by their own lane
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const u32 l = lk[k];
+        const u32 code = fl[k] + rk[k];
+        const u32 sym = (u32)k * 64u + lane;
+        const bool in_root = l <= (u32)ROOT;
+        const u32 rest = in_root ? l : l - ROOT;                // bits of the code in the table its entry goes to
+        const u32 e = sym_entry(TYPE, sym, rest);
+        const u32 i0 = l ? __brev(in_root ? code : code & ((1u << rest) - 1)) >> (32 - rest) : 0u;
+        if (l > (u32)ROOT) {
+            const u32 link = tab[__brev(code >> rest) >> (32 - ROOT)];
+            const u32 sb = e_extra(link);
+            u32 *sub = tab + ((e_val(link) - tab_lds) >> 2) - TAB_OFF;
+            for (u32 j = 0; j < (1u << sb); j += 1u << rest) sub[i0 + j] = e;
+        } else if (l >= OWN_MIN) {
+#pragma unroll
+            for (u32 j = 0; j < 4; j++)
+                if (j < (1u << (ROOT - l))) tab[i0 + (j << l)] = e;
+        }
+        for (u64 m = __ballot(l != 0 && l < OWN_MIN); m; m &= m - 1) {
+            const int src = __ffsll((long long)m) - 1;
+            const u32 e_s = (u32)__builtin_amdgcn_readlane((int)e, src);
+            const u32 i_s = (u32)__builtin_amdgcn_readlane((int)i0, src);
+            const u32 l_s = (u32)__builtin_amdgcn_readlane((int)l, src);
+            for (u32 j = lane; j < (1u << (ROOT - l_s)); j += 64) tab[i_s + (j << l_s)] = e_s;
+        }
+    }
+    if (degenerate) {
+        // the lone code's out-of-range sibling: code word 1
+        const u32 e = sym_entry(TYPE, 0xffffu, 1);
+        for (u32 j = lane; j < (1u << (ROOT - 1)); j += 64) tab[1u + 2u * j] = e;
+    }
+    wave_sync();
+#ifdef XFG_PROFILE
+    if (TYPE == XFG_PROF_TABLE && lane == 0) L.prof[PF_T_SUB] += __builtin_amdgcn_s_memtime() - bt2_;
 #endif
     return 0;
 }
@@ -831,21 +835,30 @@ __device__ __forceinline__ int read_dynamic_header_impl(Reader &r, LDS &L, u32 l
         if (fast) {
             const u32 c = (info >> 8) & 31;
             const u32 cnt = c < 16 ? 1u : (c == 18 ? 11u : 3u) + ((info >> 16) & 127);
-            const u32 info2 = ((info & 15) + ((info >> 4) & 7)) | (cnt << 8);
+            const u32 step = (info & 15) + ((info >> 4) & 7);
+            // the hops: positions only (a scalar loop of six instructions per symbol); the symbol counts come from a prefix
+            // sum over the visited lanes afterwards, and the path is cut behind the lane whose run reaches max_syms
             u64 vis = 0;
-            u32 s2 = sym;
-            while (pos < 64 && s2 < max_syms) {
-                const u32 i2 = (u32)__builtin_amdgcn_readlane((int)info2, (int)pos);
-                vis |= 1ull << pos;
-                pos += i2 & 31;
-                s2 += i2 >> 8;
+            while (pos < 64) {
+                const u32 st1 = (u32)__builtin_amdgcn_readlane((int)step, (int)pos);
+                asm("s_bitset1_b64 %0, %1" : "+s"(vis) : "s"(pos));
+                pos += st1 ? st1 : 64u;                         // (a code word is at least one bit: the loop ends whatever the table holds)
+            }
+            bool my = (vis >> lane) & 1;
+            u32 total;
+            const u32 idx = sym + wave_excl_scan(my ? cnt : 0u, total);
+            u32 s2 = sym + total;
+            if (s2 >= max_syms) {
+                const u64 reach = __ballot(my && idx + cnt >= max_syms);      // (not empty)
+                const u32 f = (u32)__ffsll((long long)reach) - 1;
+                vis &= (2ull << f) - 1;
+                my = my && lane <= f;
+                pos = f + (u32)__builtin_amdgcn_readlane((int)step, (int)f);
+                s2 = (u32)__builtin_amdgcn_readlane((int)(idx + cnt), (int)f);
             }
             // an invalid code on the path, or a repeat with nothing before it (prefix.go:139-141): the exact way
             if ((__ballot((info >> 31) != 0) & vis) || (sym == 0 && ((u32)__builtin_amdgcn_readlane((int)c, 0)) == 16)) { fast = false; pos = 0; }
             else {
-                const bool my = (vis >> lane) & 1;
-                u32 total;
-                const u32 idx = sym + wave_excl_scan(my ? cnt : 0u, total);
                 if (my && c < 16 && idx < max_syms) H.lens[idx] = (u8)c;
                 const u64 m16 = __ballot(my && c == 16);
                 const u64 mexp = __ballot(my && c < 16);             // explicit lengths
