@@ -625,7 +625,7 @@ __device__ __attribute__((noinline)) int build_table(LDS &L_, u32 *tab_, const u
 #pragma unroll
     for (int k = 0; k < NK; k++) fl[k] = L.h.first[lk[k]];
     //    Short codes have many entries (2^(ROOT - l)): those are written by the whole wave, one code after the other.
-    constexpr u32 OWN_MIN = ROOT >= 3 ? ROOT - 2 : 1;           // codes of at least this many bits (<= 4 entries) are written by their own lane
+    constexpr u32 OWN_MIN = ROOT >= 4 ? ROOT - 3 : 1;           // codes of at least this many bits (<= 8 entries) are written by their own lane
 #pragma unroll
     for (int k = 0; k < NK; k++) {
         const u32 l = lk[k];
@@ -642,7 +642,7 @@ __device__ __attribute__((noinline)) int build_table(LDS &L_, u32 *tab_, const u
             for (u32 j = 0; j < (1u << sb); j += 1u << rest) sub[i0 + j] = e;
         } else if (l >= OWN_MIN) {
 #pragma unroll
-            for (u32 j = 0; j < 4; j++)
+            for (u32 j = 0; j < 8; j++)
                 if (j < (1u << (ROOT - l))) tab[i0 + (j << l)] = e;
         }
         for (u64 m = __ballot(l != 0 && l < OWN_MIN); m; m &= m - 1) {
