@@ -835,14 +835,15 @@ __device__ __forceinline__ int read_dynamic_header_impl(Reader &r, LDS &L, u32 l
         if (fast) {
             const u32 c = (info >> 8) & 31;
             const u32 cnt = c < 16 ? 1u : (c == 18 ? 11u : 3u) + ((info >> 16) & 127);
-            const u32 step = (info & 15) + ((info >> 4) & 7);
+            u32 step = (info & 15) + ((info >> 4) & 7);
+            step = step ? step : 64u;                             // (a code word is at least one bit: the hop loop ends whatever the table holds)
             // the hops: positions only (a scalar loop of six instructions per symbol); the symbol counts come from a prefix
             // sum over the visited lanes afterwards, and the path is cut behind the lane whose run reaches max_syms
             u64 vis = 0;
             while (pos < 64) {
                 const u32 st1 = (u32)__builtin_amdgcn_readlane((int)step, (int)pos);
                 asm("s_bitset1_b64 %0, %1" : "+s"(vis) : "s"(pos));
-                pos += st1 ? st1 : 64u;                         // (a code word is at least one bit: the loop ends whatever the table holds)
+                pos += st1;
             }
             bool my = (vis >> lane) & 1;
             u32 total;
