@@ -2337,7 +2337,11 @@ inflate_chunks_kernel(const u8 *__restrict__ comp, u64 comp_len, const xfg_chunk
             const u32 round = v < m ? 0u : (v < 2u * m ? 1u : 2u);
             const u32 ci = lo + (v - round * m);
             const u64 cs = uni64(chunks[ci].comp_size), rs = uni64(chunks[ci].raw_size);
-            const u32 cls = cs * 8 >= rs * 5 ? 0u : (cs * 4 >= rs ? 1u : 2u);
+#ifndef XFG_CLASS_MERGE
+#define XFG_CLASS_MERGE 0               // 1: the two expensive classes are drawn in one round, interleaved as the table has them (tuning: match-source over-fetch)
+#endif
+            u32 cls = cs * 8 >= rs * 5 ? 0u : (cs * 4 >= rs ? 1u : 2u);
+            if (XFG_CLASS_MERGE && cls == 1) cls = 0;
             if (cls == round) inflate_chunk(comp, comp_len, chunks, ci, raw, raw_len, res, L, lane);
         }
     }
