@@ -2485,6 +2485,11 @@ int decode_waves_setting()
 }
 // workgroups of `waves` waves that one CU holds (LDS- and register-bound), per wave count; 0 = not asked yet
 std::atomic<int> g_wg_per_cu[xfg::WG_MAX_WAVES + 1];
+// 9 to 12 waves per chunk are one workgroup per CU, three waves per SIMD: the kernel compiled for that register budget
+#ifndef XFG_WG_WIDE
+#define XFG_WG_WIDE 1
+#endif
+bool wg_wide(int waves) { return XFG_WG_WIDE && waves > 8 && waves <= xfg::WG_WIDE_WAVES; }
 int wg_blocks_per_cu(int waves)
 {
     int nb = g_wg_per_cu[waves].load(std::memory_order_relaxed);
@@ -2492,7 +2497,10 @@ int wg_blocks_per_cu(int waves)
     const size_t lds = xfg::wg_lds_bytes((uint32_t)waves, xfg::wg_extra_bytes((uint32_t)waves), xfg::wg_has_ring((uint32_t)waves));
     // more than 64 KB of dynamic LDS has to be asked for
     (void)hipFuncSetAttribute((const void *)xfg::inflate_chunks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xfg::WG_LDS_MAX);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg_kernel, 64 * waves, lds) != hipSuccess || nb < 1) nb = 1;
+    (void)hipFuncSetAttribute((const void *)xfg::inflate_chunks_wg12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xfg::WG_LDS_MAX);
+    const hipError_t oe = wg_wide(waves) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg12_kernel, 64 * waves, lds)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg_kernel, 64 * waves, lds);
+    if (oe != hipSuccess || nb < 1) nb = 1;
     g_wg_per_cu[waves].store(nb, std::memory_order_relaxed);
     return nb;
 }
@@ -2531,9 +2539,14 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, co
         if (blocks > n) blocks = n;
         const uint32_t extra = xfg::wg_extra_bytes((uint32_t)waves);
         const bool ring = xfg::wg_has_ring((uint32_t)waves);
-        hipLaunchKernelGGL(xfg::inflate_chunks_wg_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves, extra, ring), stream,
-                           (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
-                           (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch, extra, ring ? 1u : 0u);
+        if (wg_wide(waves))
+            hipLaunchKernelGGL(xfg::inflate_chunks_wg12_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves, extra, ring), stream,
+                               (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
+                               (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch, extra, ring ? 1u : 0u);
+        else
+            hipLaunchKernelGGL(xfg::inflate_chunks_wg_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves, extra, ring), stream,
+                               (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
+                               (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch, extra, ring ? 1u : 0u);
         return hipGetLastError();
     }
     const uint32_t blocks = xfg_grid_blocks(n, num_cu);
