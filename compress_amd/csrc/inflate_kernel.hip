@@ -166,6 +166,15 @@ constexpr int MAX_PASSES = 6;           // speculative passes before settling fo
 #ifndef XFG_STORED_SYNC
 #define XFG_STORED_SYNC 0
 #endif
+#ifndef XFG_COUNT_FROM
+#define XFG_COUNT_FROM 3                // from this walk on (1 = the first walk from corrected starts) a lane that walks counts: dynamic blocks
+#endif
+#ifndef XFG_COUNT_FROM_LONG
+#define XFG_COUNT_FROM_LONG 1           // the same for batches of long segments (literal-heavy data)
+#endif
+#ifndef XFG_COUNT_FROM_FIXED
+#define XFG_COUNT_FROM_FIXED 99         // the same for fixed blocks (99: never)
+#endif
 #ifndef XFG_MAX_FIX_FIXED
 #define XFG_MAX_FIX_FIXED 12          // fixed blocks: every walk adds about two lanes to the chain, and costs less than a new batch
 #endif
@@ -243,7 +252,9 @@ enum { PF_HEADER = 0, PF_WINDOW, PF_COUNT, PF_EMIT, PF_RESOLVE, PF_STORED, PF_TO
        PF_C_FIX_LOST, PF_C_FLAG_CUTS, PF_C_FLAG_LOST, PF_C_CAP_CUTS, PF_C_CAP_LOST, PF_T_SORT, PF_T_ROOT, PF_T_SUB,
        PF_N_WFULL, PF_N_WF_TOK, PF_N_WF_OUT, PF_N_LONG, PF_N_LONG_G, PF_T_LONG, PF_N_INDEP, PF_N_LONG_RDY,
        // the workgroup kernel: cycles spent waiting for the wave before (chain, count), the group's outcome, the water mark; events
-       PF_W_CHAIN, PF_W_CNT, PF_W_OUT, PF_W_WATER, PF_W_GROUPS, PF_W_ABORT, PF_W_ALONE, PF_W_REFIX, PF_COUNTERS = 48 };   // lanes a batch did not keep, by cause
+       PF_W_CHAIN, PF_W_CNT, PF_W_OUT, PF_W_WATER, PF_W_GROUPS, PF_W_ABORT, PF_W_ALONE, PF_W_REFIX,
+       // lanes that walk in the first, second, third and later re-synchronisation walks of a batch (the one-wave kernel)
+       PF_N_DIRTY1, PF_N_DIRTY2, PF_N_DIRTY3, PF_N_DIRTY4, PF_COUNTERS = 56 };   // lanes a batch did not keep, by cause
 // Per-wave LDS.  The header scratch is live only while a block header is parsed and its
 // tables are built; the output window is live only while a block's tokens are decoded.
 struct HeaderScratch {
@@ -1907,6 +1918,16 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
             const u32 stopA = eA & E_STOP;
             u32 end = endA, stop = stopA;
             PROF_CNT(PF_N_PASS, 1, lane);
+            // The first XFG_COUNT_FROM - 1 walks from corrected starts are merge walks (sync_segment<true>: many lanes, most
+            // of them done after a few tokens).  From then on a lane whose start has moved walks its whole path and COUNTS
+            // (bytes and matches: stage 1a'), and so does, in the first such round, every lane that has not moved: the later
+            // re-synchronisation walks have a handful of lanes and last as long as a whole segment anyway, so the count
+            // pass that used to follow them rides along (round 3: one pass per batch less).
+            bool counted = false;                               // sg belongs to this lane's (start, dead)
+            // (literal-heavy batches, long segments: one lane in twenty fails to merge, so the first walk from corrected starts
+            // counts already; fixed blocks, where a walk adds two lanes to the chain: merge walks only, and one count pass)
+            const u32 count_from = max_fix > (u32)MAX_FIX ? (u32)XFG_COUNT_FROM_FIXED :
+                                   seg_bits == (u32)XFG_SEG_LONG ? (u32)XFG_COUNT_FROM_LONG : (u32)XFG_COUNT_FROM;
             for (int pass = 1;; pass++) {
                 const u32 pe = lane_prev(end);
                 const u32 pst = lane_prev(stop);
@@ -1916,12 +1937,18 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
                 if (lane > 0) { nd = pd != 0 || pst != 0; ns = pe; }
                 dirty = (nd != dead) || (!nd && ns != start);
                 start = ns; dead = nd;
+                if (dirty) counted = false;
+                const bool cround = (u32)pass >= count_from;
                 const u64 dm = __ballot(dirty);
-                if (dm == 0) { verified = 64; break; }
-                const u32 fd = (u32)__ffsll((long long)dm) - 1;       // lanes below fd are chained from p0
-                if ((u32)pass > max_fix || fd >= want || (pass > ACCEPT_PASS && fd >= (u32)XFG_ACCEPT_FD)) { verified = fd; break; }
-                {
+                const u64 needm = __ballot(!dead && !counted);
+                if (dm == 0 && (!cround || needm == 0)) { verified = 64; break; }
+                const u32 fd = dm ? (u32)__ffsll((long long)dm) - 1 : 64u;   // lanes below fd are chained from p0
+                if (dm && ((u32)pass > max_fix || fd >= want || (pass > ACCEPT_PASS && fd >= (u32)XFG_ACCEPT_FD))) { verified = fd; break; }
+                if (!cround) {
                     PROF_T0();
+#ifdef XFG_PROFILE
+                    { const u32 nwalk_ = (u32)__popcll(__ballot(dirty && !dead)); PROF_CNT(PF_N_DIRTY1 + (pass > 4 ? 3 : pass - 1), nwalk_, lane); }
+#endif
                     if (dirty && !dead) {
                         const u32 en = sync_segment<true, false>(L, wb0, start, seg_start, seg_bits, lane, e1, mg);
                         end = mg ? endA : en;
@@ -1929,13 +1956,30 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
                     }
                     PROF_ADD(PF_P_FIX, lane);
                     PROF_CNT(PF_N_FIX, 1, lane);
+                } else {
+                    PROF_T0();
+#ifdef XFG_PROFILE
+                    { const u32 nwalk_ = (u32)__popcll(needm); PROF_CNT(PF_N_DIRTY1 + (pass > 4 ? 3 : pass - 1), nwalk_, lane); }
+#endif
+                    if (!dead && !counted) {
+                        sg = decode_segment_fast<false>(L, tl, wb0, start, seg_end, 0, 0, 0, lane, dummy);
+                        end = sg.end;
+                        stop = sg.flag != F_NONE ? 1u : 0u;
+                        counted = true;
+                    }
+                    PROF_ADD(PF_P_COUNT, lane);
+                    PROF_CNT(PF_N_FIX, 1, lane);
                 }
                 PROF_CNT(PF_N_PASS, 1, lane);
             }
             wave_sync();                                        // the masks share LDS with the output window
-            // ---- stage 1a': count bytes and matches along the true path
-            { PROF_T0(); if (!dead && lane < verified) sg = decode_segment_fast<false>(L, tl, wb0, start, seg_end, 0, 0, 0, lane, dummy); PROF_ADD(PF_P_COUNT, lane); }
-            PROF_CNT(PF_N_PASS, 1, lane);
+            // ---- stage 1a': count bytes and matches along the true path, for the lanes that have not counted yet
+            if (__ballot(!dead && lane < verified && !counted)) {
+                PROF_T0();
+                if (!dead && lane < verified && !counted) sg = decode_segment_fast<false>(L, tl, wb0, start, seg_end, 0, 0, 0, lane, dummy);
+                PROF_ADD(PF_P_COUNT, lane);
+                PROF_CNT(PF_N_PASS, 1, lane);
+            }
             // Whatever the walks above concluded, only a chain that closes is kept: every lane must start
             // where its predecessor's counted path ended (a lane that stopped at the output cap ends early).
             const u32 pe2 = lane_prev(sg.end);

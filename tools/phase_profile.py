@@ -18,7 +18,8 @@ NAMES = ["header", "window", "count_passes", "emit_pass", "resolve", "stored", "
          "h_clen_table", "h_lens_loop", "h_lit_table", "h_dist_table", "r_sync", "r_sweep", "p_spec", "p_fix", "p_count", "n_fix",
          "c_fix_lost", "c_flag_cuts", "c_flag_lost", "c_cap_cuts", "c_cap_lost", "t_sort", "t_root", "t_sub",
          "n_wfull", "n_wf_tok", "n_wf_out", "n_long", "n_long_g", "t_long", "n_indep", "n_long_rdy",
-         "w_chain", "w_cnt", "w_out", "w_water", "w_groups", "w_abort", "w_alone", "w_refix"]
+         "w_chain", "w_cnt", "w_out", "w_water", "w_groups", "w_abort", "w_alone", "w_refix",
+         "n_dirty1", "n_dirty2", "n_dirty3", "n_dirty4"]
 
 
 def main():
@@ -32,13 +33,13 @@ def main():
         d_raw = torch.zeros(shard["raw_len"] + 64, dtype=torch.uint8, device=dev)
         d_res = torch.zeros(n * ctypes.sizeof(capi.Result), dtype=torch.uint8, device=dev)
         L = capi.lib()
-        buf = (ctypes.c_ulonglong * 48)()
+        buf = (ctypes.c_ulonglong * 56)()
         for it in range(2):
-            L.xfg_debug_profile(buf, 48)          # clear
+            L.xfg_debug_profile(buf, 56)          # clear
             ctx.decode_device(d_comp.data_ptr(), len(shard["comp"]), d_chunks.data_ptr(), n,
                               d_raw.data_ptr(), shard["raw_len"], d_res.data_ptr(), None)
             ctx.sync()
-        L.xfg_debug_profile(buf, 48)
+        L.xfg_debug_profile(buf, 56)
         v = {k: buf[i] for i, k in enumerate(NAMES)}
         tot = max(v["total"], 1)
         print("== %s: %d chunks" % (w, n))
@@ -52,6 +53,8 @@ def main():
         nb = max(v["n_batch"], 1)
         print("  walks per batch: speculative %.0f, re-synchronisation %.0f (%.2f walks), count %.0f cycles" %
               (v["p_spec"] / nb, v["p_fix"] / nb, v["n_fix"] / nb, v["p_count"] / nb))
+        print("  lanes that walk per batch: re-synchronisation walk 1: %.1f, walk 2: %.1f, walk 3: %.2f, walks 4 and later: %.2f" %
+              (v["n_dirty1"] / nb, v["n_dirty2"] / nb, v["n_dirty3"] / nb, v["n_dirty4"] / nb))
         print("  resolve per batch: wait for earlier stores %.0f, pre-window sweep %.0f" % (v["r_sync"] / nb, v["r_sweep"] / nb))
         print("  batches %d  passes/batch %.2f  live lanes/batch %.1f  rounds/batch %.1f  blocks %d" %
               (v["n_batch"], v["n_pass"] / nb, v["n_live_lanes"] / nb, v["n_rounds"] / nb, v["n_blocks"]))

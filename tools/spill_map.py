@@ -69,12 +69,19 @@ for name, a, b in funcs:
             if is_inst(lines[i]): n += 1
             m = re.match(r"\.loc\s+\d+\s+(\d+)", s)
             if m: src[int(m.group(1))] += 1
-        if not c:
+        is_walk = False
+        if lp is not None:
+            whole_ = sum(1 for i in range(lp[0], lp[1] + 1) if is_inst(lines[i]))
+            text_ = "\n".join(lines[lp[0]:lp[1] + 1])
+            is_walk = whole_ < 400 and "ds_read_b64" in text_ and "v_bitop3" in text_ and "v_lshrrev_b64" in text_
+        if not c and not is_walk:
             continue
         top = ", ".join("%d" % l for l, _ in src.most_common(6))
         if lp is None:
             print("   outside any loop (%d own instructions): %s" % (n, dict(c)))
         else:
             whole = sum(1 for i in range(lp[0], lp[1] + 1) if is_inst(lines[i]))
+            text = "\n".join(lines[lp[0]:lp[1] + 1])
+            walk = " [a walk loop: bit-buffer top-up + table look-up]" if whole < 400 and "ds_read_b64" in text and "v_bitop3" in text and "v_lshrrev_b64" in text else ""
             depth = sum(1 for (s, e) in loops if s <= lp[0] and lp[1] <= e)
-            print("   loop asm %d-%d depth %d, %d instructions (%d its own), source lines mostly %s: %s" % (lp[0] + 1, lp[1] + 1, depth, whole, n, top, dict(c)))
+            print("   loop asm %d-%d depth %d, %d instructions (%d its own), source lines mostly %s%s: %s" % (lp[0] + 1, lp[1] + 1, depth, whole, n, top, walk, dict(c)))
