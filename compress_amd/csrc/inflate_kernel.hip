@@ -172,6 +172,9 @@ constexpr int MAX_PASSES = 6;           // speculative passes before settling fo
 #ifndef XFG_COUNT_FROM_LONG
 #define XFG_COUNT_FROM_LONG 1           // the same for batches of long segments (literal-heavy data)
 #endif
+#ifndef XFG_COUNT_FROM_RUN
+#define XFG_COUNT_FROM_RUN 99           // the same for batches of runs and long matches (their long codes with many extra bits synchronise badly: many lanes walk in every round, and merge walks end early)
+#endif
 #ifndef XFG_COUNT_FROM_FIXED
 #define XFG_COUNT_FROM_FIXED 99         // the same for fixed blocks (99: never)
 #endif
@@ -1927,7 +1930,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
             // (literal-heavy batches, long segments: one lane in twenty fails to merge, so the first walk from corrected starts
             // counts already; fixed blocks, where a walk adds two lanes to the chain: merge walks only, and one count pass)
             const u32 count_from = max_fix > (u32)MAX_FIX ? (u32)XFG_COUNT_FROM_FIXED :
-                                   seg_bits == (u32)XFG_SEG_LONG ? (u32)XFG_COUNT_FROM_LONG : (u32)XFG_COUNT_FROM;
+                                   seg_bits == (u32)XFG_SEG_LONG ? (u32)XFG_COUNT_FROM_LONG :
+                                   seg_bits == (u32)XFG_SEG_RUN ? (u32)XFG_COUNT_FROM_RUN : (u32)XFG_COUNT_FROM;
             for (int pass = 1;; pass++) {
                 const u32 pe = lane_prev(end);
                 const u32 pst = lane_prev(stop);
@@ -1963,8 +1967,13 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
 #endif
                     if (!dead && !counted) {
                         sg = decode_segment_fast<false>(L, tl, wb0, start, seg_end, 0, 0, 0, lane, dummy);
-                        end = sg.end;
-                        stop = sg.flag != F_NONE ? 1u : 0u;
+                        // A lane that stopped at its output cap hands its end to its successor only if it got through
+                        // most of its segment: where a few tokens fill the cap (runs), every round would add one lane
+                        // to the chain; there the chain is cut behind this lane (the closure test below), as before.
+                        if (sg.flag != F_NONE || sg.end + seg_bits / 2 >= seg_end) {
+                            end = sg.end;
+                            stop = sg.flag != F_NONE ? 1u : 0u;
+                        }
                         counted = true;
                     }
                     PROF_ADD(PF_P_COUNT, lane);
