@@ -52,6 +52,20 @@ def measured_traffic(workload):
             continue
     return None
 
+
+def stream_traffic(algo_bytes_per_gpu):
+    """The 32 GiB stream's launches (c3_stream: one GPU's record range) have no counter pass of their own -- the driver
+    runs them on N GPUs; their chunks are the c3 workload's (the same 384 distinct 256 KiB chunks, tiled), so the
+    traffic of c3's launch is scaled by the algorithmic bytes of this launch.  Stated in roofline.traffic_note."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r3", "traffic.json")))["c3"]
+        b = json.load(open(os.path.join(ROOT, "profiles", "r3", "traffic_c3_bench.json")))
+        ref_algo = b["roofline"]["algorithmic_bytes_per_launch"]
+        ref = (t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024 + t["comp_bytes"] // 2
+        return int(ref * (algo_bytes_per_gpu / ref_algo))
+    except (OSError, KeyError, ValueError):
+        return None
+
 WORKLOADS = {
     # name: (chunks per GPU, chunk size, kinds, zlib level, distinct chunks generated)
     "c2": (16384, 65536, ("huffman", "repeats", "digits"), 6, 768),
@@ -434,11 +448,15 @@ def main():
                         "raw_bytes_per_gpu": raw_len, "comp_bytes_per_gpu": comp_len,
                         "ratio": round(raw_len / comp_len, 3), "verified_bit_exact": verified}),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": stream_traffic(algo_bytes / world) if is_stream else measured_traffic(args.workload),
                          "kernel": "inflate_chunks_kernel" if waves_per_chunk == 1 else "inflate_chunks_wg_kernel",
                          "waves_per_chunk": waves_per_chunk, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes if world == 1 else int(algo_bytes / world),
-                         "per": "GPU (achieved and peak are per GPU; launches of all ranks run side by side)"},
+                         "per": "GPU (achieved and peak are per GPU; launches of all ranks run side by side)",
+                         "traffic_note": ("per GPU: the counter passes of the c3 workload (the same 256 KiB chunks, 16 384 per launch; profiles/r3/traffic.json) "
+                                          "scaled by this launch's algorithmic bytes" if is_stream else
+                                          "per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command (profiles/r3/traffic.json, tools/traffic_pass.sh)")},
         }
         if not args.no_cpu and world == 1:                  # the CPU leg runs at N=1 only
             import oracle
