@@ -76,6 +76,12 @@ WORKLOADS = {
     "c3_stream_small": (8192, 262144, ("huffman", "repeats", "digits"), 6, 96),   # the same path at 2 GiB (rehearsals, tests)
     "c2x4": (65536, 65536, ("huffman", "repeats", "digits"), 6, 768),    # diagnostic: how much of c2's time is the grid's tail
     # diagnostics for the workgroup-per-chunk mode: few chunks, one data shape each
+    "mid1k": (1024, 65536, ("huffman", "repeats", "digits"), 6, 192),
+    "mid2k": (2048, 65536, ("huffman", "repeats", "digits"), 6, 192),
+    "mid3k": (3072, 65536, ("huffman", "repeats", "digits"), 6, 192),
+    "mid4k": (4096, 65536, ("huffman", "repeats", "digits"), 6, 192),
+    "mid6k": (6144, 65536, ("huffman", "repeats", "digits"), 6, 192),
+    "mid8k": (8192, 65536, ("huffman", "repeats", "digits"), 6, 192),
     "small_huffman": (768, 65536, ("huffman",), 6, 96),
     "small_repeats": (768, 65536, ("repeats",), 6, 96),
     "small_digits": (768, 65536, ("digits",), 6, 96),

@@ -2576,7 +2576,13 @@ extern "C" int xfg_decode_waves_for(uint32_t n, int num_cu)
     // Measured (profiles/r3/wg_wave_sweep.txt): 12 waves (one workgroup per CU, the history ring in LDS) where the
     // chunks are few enough for that; otherwise 4 (four workgroups per CU) -- 5 to 8 waves per chunk lose to 4 on
     // every shape; 3 or 2 when there are more chunks than that.
-    return w >= 12 ? 12 : w >= 4 ? 4 : w >= 2 ? (int)w : 1;
+    // Two waves per chunk still win with somewhat more chunks than wave slots (the workgroups that do not fit wait their
+    // turn): 4096 chunks 144 -> 156 GB/s, 3072 chunks 126 -> 147; from about 1.5 chunks per slot on one wave per chunk
+    // is faster (6144 chunks: 188 against 167; profiles/r3/wg_wave_policy.txt).
+    if (w >= 12) return 12;
+    if (w >= 4) return 4;
+    if (w >= 2) return (int)w;
+    return (uint64_t)n * 4 <= slots * 5 ? 2 : 1;
 }
 
 extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, const void *d_chunks, uint32_t n,
