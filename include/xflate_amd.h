@@ -163,9 +163,9 @@ int xfg_decode_device_noalloc(int device, const void *d_comp, size_t comp_len,
 /*
  * How many wavefronts decode one chunk.  No counterpart in the reference (whose Reader decodes one chunk at a
  * time on one goroutine, xflate/reader.go:162-215); a tuning and test knob.  0 (the default, or what the
- * environment variable XFG_DECODE_WAVES says): chosen per launch from the chunk count -- a table with at least
- * half as many chunks as the GPU has wave slots (4096 on MI355X) gives every chunk one wavefront, a smaller one
- * gives every chunk a workgroup of up to 16 wavefronts that decode consecutive batches of the chunk's blocks
+ * environment variable XFG_DECODE_WAVES says): chosen per launch from the chunk count -- a table with more than
+ * 1.25 chunks per wave slot of the GPU (4096 slots on MI355X) gives every chunk one wavefront, a smaller one
+ * gives every chunk a workgroup of 2, 3, 4 or 12 wavefronts that decode consecutive batches of the chunk's blocks
  * together (a Reader's window, flate.NewReader's single stream, a few huge chunks).  1: always one wavefront.
  * 2..16: always a workgroup of that many.  Results are bit-identical whatever the setting.  Process-wide; returns
  * XFG_E_ARG for any other value.  xfg_decode_waves_for() says what a launch of n chunks would use.
