@@ -2537,24 +2537,34 @@ int decode_waves_setting()
     return w;
 }
 // workgroups of `waves` waves that one CU holds (LDS- and register-bound), per wave count; 0 = not asked yet
-std::atomic<int> g_wg_per_cu[xfg::WG_MAX_WAVES + 1];
+std::atomic<int> g_wg_per_cu[2][xfg::WG_MAX_WAVES + 1];
 // 9 to 12 waves per chunk are one workgroup per CU, three waves per SIMD: the kernel compiled for that register budget
 #ifndef XFG_WG_WIDE
 #define XFG_WG_WIDE 1
 #endif
-bool wg_wide(int waves) { return XFG_WG_WIDE && waves > 8 && waves <= xfg::WG_WIDE_WAVES; }
-int wg_blocks_per_cu(int waves)
+// ... and so are fewer waves per chunk when all the launch's workgroups fit the chip at three waves per SIMD (768 chunks
+// of four waves: 12 waves on each of 256 CUs): the 128-register build spills inside its group loop
+#ifndef XFG_WG_WIDE_SMALL
+#define XFG_WG_WIDE_SMALL 1
+#endif
+bool wg_wide(int waves, uint32_t n, int num_cu)
 {
-    int nb = g_wg_per_cu[waves].load(std::memory_order_relaxed);
+    if (!XFG_WG_WIDE || waves > xfg::WG_WIDE_WAVES) return false;
+    if (waves > 8) return true;
+    return XFG_WG_WIDE_SMALL && (uint64_t)n * (uint64_t)waves <= (uint64_t)num_cu * (12 / waves) * waves;
+}
+int wg_blocks_per_cu(int waves, bool wide)
+{
+    int nb = g_wg_per_cu[wide ? 1 : 0][waves].load(std::memory_order_relaxed);
     if (nb > 0) return nb;
     const size_t lds = xfg::wg_lds_bytes((uint32_t)waves, xfg::wg_extra_bytes((uint32_t)waves), xfg::wg_has_ring((uint32_t)waves));
     // more than 64 KB of dynamic LDS has to be asked for
     (void)hipFuncSetAttribute((const void *)xfg::inflate_chunks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xfg::WG_LDS_MAX);
     (void)hipFuncSetAttribute((const void *)xfg::inflate_chunks_wg12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xfg::WG_LDS_MAX);
-    const hipError_t oe = wg_wide(waves) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg12_kernel, 64 * waves, lds)
-                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg_kernel, 64 * waves, lds);
+    const hipError_t oe = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg12_kernel, 64 * waves, lds)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xfg::inflate_chunks_wg_kernel, 64 * waves, lds);
     if (oe != hipSuccess || nb < 1) nb = 1;
-    g_wg_per_cu[waves].store(nb, std::memory_order_relaxed);
+    g_wg_per_cu[wide ? 1 : 0][waves].store(nb, std::memory_order_relaxed);
     return nb;
 }
 }
@@ -2594,11 +2604,12 @@ extern "C" hipError_t xfg_launch_inflate(const void *d_comp, size_t comp_len, co
     if (e != hipSuccess) return e;
     const int waves = xfg_decode_waves_for(n, num_cu);
     if (waves >= 2) {
-        uint32_t blocks = (uint32_t)num_cu * (uint32_t)wg_blocks_per_cu(waves);
+        const bool wide = wg_wide(waves, n, num_cu);
+        uint32_t blocks = (uint32_t)num_cu * (uint32_t)wg_blocks_per_cu(waves, wide);
         if (blocks > n) blocks = n;
         const uint32_t extra = xfg::wg_extra_bytes((uint32_t)waves);
         const bool ring = xfg::wg_has_ring((uint32_t)waves);
-        if (wg_wide(waves))
+        if (wide)
             hipLaunchKernelGGL(xfg::inflate_chunks_wg12_kernel, dim3(blocks), dim3(64 * waves), xfg::wg_lds_bytes((uint32_t)waves, extra, ring), stream,
                                (const uint8_t *)d_comp, (uint64_t)comp_len, (const xfg_chunk *)d_chunks, n,
                                (uint8_t *)d_raw, (uint64_t)raw_len, (xfg_result *)d_res, (uint32_t *)d_scratch, extra, ring ? 1u : 0u);
