@@ -18,6 +18,9 @@
 //            c. count pass along the true path (bytes and matches per lane); wave
 //               prefix sums give output and token offsets.  Only a chain that closes
 //               (every lane starts where its predecessor's counted path ended) is kept.
+//               The late walks of b. do this counting themselves (XFG_COUNT_FROM): a lane whose
+//               start moved walks its whole path and counts, every other lane counts in the
+//               first such round, and the separate pass runs for what is left.
 //            d. emit pass: literals to their final positions in an LDS output window,
 //               match tokens to a list in LDS.
 //            Every walk is one table lookup per step (literal/length root, distance
