@@ -50,6 +50,15 @@ def test_setting_is_checked():
     assert L.xfg_decode_waves_for(1, 256) == 12
     assert L.xfg_decode_waves_for(1024, 256) in (2, 3, 4)
     assert L.xfg_decode_waves_for(1 << 14, 256) == 1
+    # two wavefronts per chunk up to 1.25 chunks per wave slot (profiles/r3/wg_wave_policy.txt), one beyond
+    import ctypes
+    L.xfg_grid_blocks.argtypes, L.xfg_grid_blocks.restype = [ctypes.c_uint32, ctypes.c_int], ctypes.c_uint32
+    slots = int(L.xfg_grid_blocks(1 << 20, 256))                # the persistent grid of the one-wave kernel: the chip's wave slots (4096)
+    assert L.xfg_decode_waves_for(slots, 256) == 2
+    assert L.xfg_decode_waves_for(slots * 5 // 4, 256) == 2
+    assert L.xfg_decode_waves_for(slots * 5 // 4 + 1, 256) == 1
+    assert L.xfg_decode_waves_for(slots // 4, 256) == 4
+    assert L.xfg_decode_waves_for(slots // 12, 256) == 12
     assert L.xfg_set_decode_waves(3) == capi.XFG_OK
     assert L.xfg_decode_waves_for(1 << 14, 256) == 3
     assert L.xfg_set_decode_waves(0) == capi.XFG_OK
