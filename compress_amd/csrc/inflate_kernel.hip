@@ -1224,7 +1224,7 @@ __device__ __forceinline__ Seg decode_segment_fast(LDS &L, const TokList tl, i32
 //                  marked position: from that point on it would repeat the speculative path, so
 //                  that path's end is its end (returns merged = true), or until its own end.
 // Returns the bit position after the last token; e_out = the entry that ended the walk.
-template <bool CHECK, bool RUNIN, class LDS>
+template <bool CHECK, bool RUNIN, bool MARK = true, class LDS>
 __device__ __forceinline__ u32 sync_segment(LDS &L, i32 wb0, u32 start, u32 seg_start, u32 seg_bits, u32 lane,
                                             u32 &e_out, bool &merged, u32 keep_stop = ~0u)
 {
@@ -1252,7 +1252,7 @@ __device__ __forceinline__ u32 sync_segment(LDS &L, i32 wb0, u32 start, u32 seg_
     u32 tb = tab0, tw = LIT_ROOT;
     u32 e = 0, hit = 0;
     u32 tokprev = ~0u;                                          // the walk starts at a token boundary
-    if (!CHECK && (i32)rel >= 0) *MROW(rel) = 1u << (rel & 31);   // rows were cleared: a plain store
+    if (!CHECK && MARK && (i32)rel >= 0) *MROW(rel) = 1u << (rel & 31);   // rows were cleared: a plain store
     for (;;) {
         buf |= nextw << cnt;
         wp += (63 - cnt) >> 3;
@@ -1276,7 +1276,7 @@ __device__ __forceinline__ u32 sync_segment(LDS &L, i32 wb0, u32 start, u32 seg_
                 if (hit) return true;                           // nothing of this step counts
             }
             buf >>= take; cnt -= take; rel += take;
-            if (!CHECK) {
+            if (!CHECK && MARK) {
                 // a token starts at rel (words past the segment exist; nobody tests them); positions
                 // before the segment (the run-in, rel < 0) are nobody's start and are not marked
                 if (RUNIN) {
@@ -1884,8 +1884,16 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
             // ---- stage 1a: find every lane's true start.  One speculative walk per lane from its segment
             // boundary, then walks from the predecessor's end that stop as soon as they meet the lane's
             // own speculative path (prefix codes self-synchronise), until the chain of starts is stable.
+            // (where the first walk from corrected starts counts already -- literal-heavy batches -- nobody ever reads the
+            // marks: the speculative walk leaves them out, five VALU and an LDS atomic per step less)
+            const u32 count_from = max_fix > (u32)MAX_FIX ? (u32)XFG_COUNT_FROM_FIXED :
+                                   seg_bits == (u32)XFG_SEG_LONG ? (u32)XFG_COUNT_FROM_LONG :
+                                   seg_bits == (u32)XFG_SEG_RUN ? (u32)XFG_COUNT_FROM_RUN : (u32)XFG_COUNT_FROM;
+            const bool marks = count_from > 1;
+            if (marks) {
 #pragma unroll
-            for (int w = 0; w < MASK_WORDS; w++) L.mask[w * 64 + lane] = 0;
+                for (int w = 0; w < MASK_WORDS; w++) L.mask[w * 64 + lane] = 0;
+            }
             u32 eA, e1;
             bool mg;
             u32 endA;
@@ -1914,7 +1922,8 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
 #endif
                 } else {
 #if XFG_SPEC_WALK_ON_DYNAMIC
-                    endA = sync_segment<false, false>(L, wb0, start, seg_start, seg_bits, lane, eA, mg, lane == 0 ? ~0u : 0u);
+                    if (marks) endA = sync_segment<false, false>(L, wb0, start, seg_start, seg_bits, lane, eA, mg, lane == 0 ? ~0u : 0u);
+                    else       endA = sync_segment<false, false, false>(L, wb0, start, seg_start, seg_bits, lane, eA, mg, lane == 0 ? ~0u : 0u);
 #else
                     endA = sync_segment<false, false>(L, wb0, start, seg_start, seg_bits, lane, eA, mg);
 #endif
@@ -1932,9 +1941,6 @@ __device__ BlockEnd decode_huffman_block(const Reader &r, Out &o, LDS &L, u32 la
             bool counted = false;                               // sg belongs to this lane's (start, dead)
             // (literal-heavy batches, long segments: one lane in twenty fails to merge, so the first walk from corrected starts
             // counts already; fixed blocks, where a walk adds two lanes to the chain: merge walks only, and one count pass)
-            const u32 count_from = max_fix > (u32)MAX_FIX ? (u32)XFG_COUNT_FROM_FIXED :
-                                   seg_bits == (u32)XFG_SEG_LONG ? (u32)XFG_COUNT_FROM_LONG :
-                                   seg_bits == (u32)XFG_SEG_RUN ? (u32)XFG_COUNT_FROM_RUN : (u32)XFG_COUNT_FROM;
             for (int pass = 1;; pass++) {
                 const u32 pe = lane_prev(end);
                 const u32 pst = lane_prev(stop);
